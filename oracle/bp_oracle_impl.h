@@ -1,0 +1,173 @@
+/*
+ * TEST INFRASTRUCTURE -- NOT PART OF THE PRODUCT PATH.
+ *
+ * Body of the binary-BP CPU oracle, included twice by bp_oracle.c with
+ *   REAL = double, SFX = f64   and   REAL = float, SFX = f32.
+ *
+ * What it restates: the `bp_decoder.decode()` loop of the third-party package
+ * ldpc==0.1.3 (simulate-with-python/requirements.txt:8) that the reference calls
+ * at simulate/decode.py:155-161,171 and simulate/hqc.py:694-699,708.  That
+ * package's source is NOT under /root/reference and is not installable here, so
+ * this follows its published algorithm as recorded in SURVEY.md Appendix A:
+ * flooding schedule; per iteration all checks, then all variables, then hard
+ * decision, then H*e == s => converged; row entries visited in ascending
+ * column, column entries in ascending row (mod2sparse order); exclusive
+ * forward/backward sweeps (no "total divided/minus self").
+ *
+ *   method 0  "product_sum"      probability-ratio domain (what the reference
+ *                                always selects): r = p/(1-p)
+ *   method 1  "min_sum"(_log)    LLR domain, running two-sided min, sign count
+ *                                where a message <= 0 counts as negative
+ *   method 2  "product_sum_log"  LLR domain tanh rule
+ *
+ * Parity status: pinned for HARD DECISIONS by the reference's three doctests
+ * (decode.py:139-149; hqc.py:1229-1274; hqc.py:1277-1311) -- see
+ * tests/test_oracle_pins.py.  Posterior LLR values are "parity unpinned": no
+ * reference fixture holds any.
+ */
+
+#define CAT_(a, b) a##_##b
+#define CAT(a, b) CAT_(a, b)
+#define FN(name) CAT(name, SFX)
+
+/* one codeword; graph in CSR (edge id = CSR position) + CSC permutation */
+int FN(oracle_bp_decode)(int m, int n, const int32_t *row_ptr, const int32_t *col_idx,
+                         const int32_t *col_ptr, const int32_t *csc_edge,
+                         const double *channel_probs, const uint8_t *synd, int max_iter,
+                         int method, double alpha_in, uint8_t *out_bits, REAL *out_llr,
+                         int32_t *out_iter, int32_t *out_converged, REAL *work /* 2*nnz */)
+{
+    const int nnz = row_ptr[m];
+    REAL *b2c = work;        /* bit_to_check   */
+    REAL *c2b = work + nnz;  /* check_to_bit   */
+    int *esgn = (int *)malloc(sizeof(int) * (size_t)(nnz > 0 ? nnz : 1));
+    if (!esgn) return -1;
+    if (max_iter <= 0) max_iter = n;
+
+    /* initial bit-to-check messages */
+    for (int j = 0; j < n; j++) {
+        REAL p = (REAL)channel_probs[j];
+        REAL init = (method == 0) ? p / ((REAL)1 - p) : RLOG(((REAL)1 - p) / p);
+        for (int t = col_ptr[j]; t < col_ptr[j + 1]; t++) b2c[csc_edge[t]] = init;
+    }
+    for (int j = 0; j < n; j++) out_bits[j] = 0;
+    *out_converged = 0;
+    *out_iter = 0;
+
+    for (int it = 1; it <= max_iter; it++) {
+        /* ---- check-to-bit ---- */
+        if (method == 0) {
+            for (int i = 0; i < m; i++) {
+                REAL temp = synd[i] ? (REAL)-1 : (REAL)1;
+                for (int e = row_ptr[i]; e < row_ptr[i + 1]; e++) {
+                    c2b[e] = temp;
+                    temp *= (REAL)2 / ((REAL)1 + b2c[e]) - (REAL)1;
+                }
+                temp = (REAL)1;
+                for (int e = row_ptr[i + 1] - 1; e >= row_ptr[i]; e--) {
+                    c2b[e] *= temp;
+                    c2b[e] = ((REAL)1 - c2b[e]) / ((REAL)1 + c2b[e]);
+                    temp *= (REAL)2 / ((REAL)1 + b2c[e]) - (REAL)1;
+                }
+            }
+        } else if (method == 2) {
+            for (int i = 0; i < m; i++) {
+                REAL temp = (REAL)1;
+                for (int e = row_ptr[i]; e < row_ptr[i + 1]; e++) {
+                    c2b[e] = temp;
+                    temp *= RTANH(b2c[e] / (REAL)2);
+                }
+                temp = (REAL)1;
+                REAL sg = synd[i] ? (REAL)-1 : (REAL)1;
+                for (int e = row_ptr[i + 1] - 1; e >= row_ptr[i]; e--) {
+                    c2b[e] *= temp;
+                    c2b[e] = sg * RLOG(((REAL)1 + c2b[e]) / ((REAL)1 - c2b[e]));
+                    temp *= RTANH(b2c[e] / (REAL)2);
+                }
+            }
+        } else { /* min-sum */
+            REAL alpha = (alpha_in == 0.0) ? (REAL)(1.0 - pow(2.0, -1.0 * it)) : (REAL)alpha_in;
+            for (int i = 0; i < m; i++) {
+                REAL temp = RBIG;
+                int sgn = synd[i] ? 1 : 0;
+                for (int e = row_ptr[i]; e < row_ptr[i + 1]; e++) {
+                    c2b[e] = temp;
+                    esgn[e] = sgn;
+                    REAL a = RABS(b2c[e]);
+                    if (a < temp) temp = a;
+                    if (b2c[e] <= (REAL)0) sgn += 1;
+                }
+                temp = RBIG;
+                sgn = 0;
+                for (int e = row_ptr[i + 1] - 1; e >= row_ptr[i]; e--) {
+                    if (temp < c2b[e]) c2b[e] = temp;
+                    esgn[e] += sgn;
+                    c2b[e] *= ((esgn[e] & 1) ? (REAL)-1 : (REAL)1) * alpha;
+                    REAL a = RABS(b2c[e]);
+                    if (a < temp) temp = a;
+                    if (b2c[e] <= (REAL)0) sgn += 1;
+                }
+            }
+        }
+
+        /* ---- bit-to-check, posterior, hard decision ---- */
+        if (method == 0) {
+            for (int j = 0; j < n; j++) {
+                REAL p = (REAL)channel_probs[j];
+                REAL temp = p / ((REAL)1 - p);
+                for (int t = col_ptr[j]; t < col_ptr[j + 1]; t++) {
+                    int e = csc_edge[t];
+                    b2c[e] = temp;
+                    temp *= c2b[e];
+                    if (temp != temp) temp = (REAL)1;
+                }
+                out_llr[j] = RLOG((REAL)1 / temp);
+                out_bits[j] = (temp >= (REAL)1) ? 1 : 0;
+                temp = (REAL)1;
+                for (int t = col_ptr[j + 1] - 1; t >= col_ptr[j]; t--) {
+                    int e = csc_edge[t];
+                    b2c[e] *= temp;
+                    temp *= c2b[e];
+                    if (temp != temp) temp = (REAL)1;
+                }
+            }
+        } else {
+            for (int j = 0; j < n; j++) {
+                REAL p = (REAL)channel_probs[j];
+                REAL temp = RLOG(((REAL)1 - p) / p);
+                for (int t = col_ptr[j]; t < col_ptr[j + 1]; t++) {
+                    int e = csc_edge[t];
+                    b2c[e] = temp;
+                    temp += c2b[e];
+                }
+                out_llr[j] = temp;
+                out_bits[j] = (temp <= (REAL)0) ? 1 : 0;
+                temp = (REAL)0;
+                for (int t = col_ptr[j + 1] - 1; t >= col_ptr[j]; t--) {
+                    int e = csc_edge[t];
+                    b2c[e] += temp;
+                    temp += c2b[e];
+                }
+            }
+        }
+
+        /* ---- convergence: H * e == s ---- */
+        *out_iter = it;
+        int ok = 1;
+        for (int i = 0; i < m && ok; i++) {
+            int par = 0;
+            for (int e = row_ptr[i]; e < row_ptr[i + 1]; e++) par ^= out_bits[col_idx[e]];
+            if (par != (synd[i] & 1)) ok = 0;
+        }
+        if (ok) {
+            *out_converged = 1;
+            break;
+        }
+    }
+    free(esgn);
+    return 0;
+}
+
+#undef FN
+#undef CAT
+#undef CAT_

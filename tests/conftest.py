@@ -1,0 +1,38 @@
+import importlib
+import json
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
+
+
+@pytest.fixture(scope="session")
+def scaldpc():
+    return importlib.import_module("sca-ldpc_amd")
+
+
+@pytest.fixture(scope="session")
+def golden():
+    out = {}
+    for f in os.listdir(GOLDEN):
+        if f.endswith(".json"):
+            with open(os.path.join(GOLDEN, f)) as fh:
+                out[f[:-5]] = json.load(fh)
+    return out
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    from oracle import pyoracle
+
+    pyoracle.lib()
+    return pyoracle

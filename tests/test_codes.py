@@ -1,0 +1,132 @@
+"""Host-side code constructors vs matrices minted from the reference's own
+generators (tests/golden/generators.json, made by tests/golden/make_fixtures.py
+from simulate/make_code.py and simulate/distance_spectrum.py)."""
+import numpy as np
+import pytest
+
+
+def same(g, coo):
+    from importlib import import_module
+
+    T = import_module("sca-ldpc_amd").TannerGraph
+    ref = T.from_coo(coo)
+    return (
+        g.m == ref.m and g.n == ref.n
+        and np.array_equal(g.row_ptr, ref.row_ptr)
+        and np.array_equal(g.col_idx, ref.col_idx)
+        and np.array_equal(g.val, ref.val)
+    )
+
+
+def test_fixed_weight_vec(scaldpc, golden):
+    c = scaldpc.codes
+    sup = c.fixed_weight_support(10, 3, c.make_random_state(0))
+    assert list(np.nonzero(golden["generators"]["fixed_weight_vec_10_3_s0"])[0]) == list(sup)
+
+
+def test_make_random_state_contract(scaldpc):
+    # simulate/utils.py:24-32
+    rng = scaldpc.codes.make_random_state(0)
+    assert rng.randint(0, 100) == 44
+    assert scaldpc.codes.make_random_state(rng).randint(0, 100) == 47
+
+
+@pytest.mark.parametrize("key,args", [
+    ("regular_6_4_2_3_s0", (6, 4, 2, 3, 0)),
+    ("regular_300_150_3_6_s0", (300, 150, 3, 6, 0)),
+])
+def test_regular(scaldpc, golden, key, args):
+    c = scaldpc.codes
+    g = c.make_regular_ldpc_graph(*args[:4], c.make_random_state(args[4]))
+    assert same(g, golden["generators"][key])
+
+
+@pytest.mark.parametrize("key,args", [
+    ("regular_identity_6_4_2_3_s0", (6, 4, 2, 3, 0)),
+    ("regular_identity_300_150_3_6_s0", (300, 150, 3, 6, 0)),
+    ("regular_identity_300_150_3_6_s1", (300, 150, 3, 6, 1)),
+])
+def test_regular_identity(scaldpc, golden, key, args):
+    c = scaldpc.codes
+    g = c.make_regular_ldpc_identity_graph(*args[:4], c.make_random_state(args[4]))
+    assert same(g, golden["generators"][key])
+
+
+def test_rng_stream_after_regular(scaldpc, golden):
+    # the q-ary doctest (decode.py:192-209) keeps drawing from the rng that built H
+    c = scaldpc.codes
+    rng = c.make_random_state(1)
+    c.make_regular_ldpc_identity_graph(300, 150, 3, 6, rng)
+    assert np.array_equal(rng.rand(1350), np.array(golden["generators"]["rand_after_regular_identity_300_150_3_6_s1"]))
+
+
+@pytest.mark.parametrize("key,args", [("qc_6_2_2_s0", (6, 2, 2)), ("qc_500_3_2_s0", (500, 3, 2))])
+def test_qc(scaldpc, golden, key, args):
+    c = scaldpc.codes
+    assert same(c.make_qc_parity_check_graph(*args, c.make_random_state(0)), golden["generators"][key])
+
+
+def test_random_ldpc_circulant(scaldpc, golden):
+    c = scaldpc.codes
+    sup = c.make_random_ldpc_first_row(10, 3, c.make_random_state(0))
+    g = c.circulant_graph(sup, 10)
+    assert same(g, golden["generators"]["random_ldpc_10_3_s0"])
+    assert same(g.with_identity(), golden["generators"]["random_ldpc_identity_10_3_s0"])
+
+
+def test_distance_spectrum(scaldpc, golden):
+    c = scaldpc.codes
+    d = golden["generators"]["ds_10_3_1_then_10_4_2_s0"]
+    rng = c.make_random_state(0)
+    s1 = c.gen_support_ds_multiplicity(10, 3, 1, rng)
+    s2 = c.gen_support_ds_multiplicity(10, 4, 2, rng)
+    assert list(s1) == list(np.nonzero(d["a1"])[0]) and list(s2) == list(np.nonzero(d["a2"])[0])
+    assert list(c.calc_ds(s1, 10)) == d["ds1"] and list(c.calc_ds(s2, 10)) == d["ds2"]
+
+
+@pytest.mark.parametrize("N,W", [(17669, 20), (17669, 50), (35851, 50), (57637, 50), (57637, 60)])
+def test_hqc_first_rows(scaldpc, golden, N, W):
+    c = scaldpc.codes
+    sup = c.make_random_ldpc_first_row(N, W, c.make_random_state(0))
+    assert list(sup) == golden["hqc_first_rows"][f"N{N}_W{W}_s0"]
+    assert c.calc_ds(sup, N).max() <= 1
+
+
+@pytest.mark.parametrize("cb", [1, 2])
+def test_qary_qc(scaldpc, golden, cb):
+    c = scaldpc.codes
+    g = c.make_qary_qc_graph(256, 6, 3, c.make_random_state(0), cb)
+    assert same(g, golden["generators"][f"qary_qc_256_6_3_s0_cb{cb}"])
+    assert g.row_degrees().max() == 7
+
+
+def test_hqc_decode_test_inputs(scaldpc, golden):
+    # hqc.py:1277-1311: y drawn first, then the first row, from one rng
+    c = scaldpc.codes
+    t = golden["hqc_decode_tests"]["full"]
+    rng = c.make_random_state(0)
+    y = rng.choice(t["N"], t["OMEGA"], replace=False)
+    sup = c.make_random_ldpc_first_row(t["N"], t["W"], rng)
+    assert [int(v) for v in y] == t["y_sparse"] and list(sup) == t["first_row"]
+
+
+def test_graph_roundtrip(scaldpc):
+    rng = np.random.RandomState(3)
+    H = (rng.rand(7, 12) < 0.3).astype(int)
+    g = scaldpc.TannerGraph.from_dense(H)
+    assert np.array_equal(g.to_dense(), H)
+    x = rng.randint(0, 2, size=(5, 12))
+    assert np.array_equal(g.syndrome(x), (x @ H.T) % 2)
+    assert np.array_equal(g.syndrome(x[0]), (H @ x[0]) % 2)
+    # CSC permutation: column-major, ascending row
+    for j in range(12):
+        e = g.csc_edge[g.col_ptr[j]:g.col_ptr[j + 1]]
+        assert (g.col_idx[e] == j).all() and (np.diff(g.csc_row[g.col_ptr[j]:g.col_ptr[j + 1]]) > 0).all()
+    gi = g.with_identity()
+    assert np.array_equal(gi.to_dense(), np.concatenate([H, np.eye(7, dtype=int)], axis=1))
+
+
+def test_rep_code(scaldpc):
+    g = scaldpc.codes.rep_code_graph(13)
+    H = g.to_dense()
+    assert H.shape == (12, 13) and (H.sum(1) == 2).all() and all(H[i, i] == 1 and H[i, i + 1] == 1 for i in range(12))
