@@ -1,0 +1,224 @@
+#!/usr/bin/env python3
+"""bench.py -- BASELINE.json's metric on BASELINE config 2, on N MI355X of one node.
+
+  metric    directed edge-message updates / s = 2*E*batch*iters / t  
+  workload  HQC-128 graph (N=17669, W=50, R=4000, H=[Hin|I], E=204000), batch 4096
+            codewords per GPU, 50 fixed iterations, fp32 min-sum, alpha=1
+  step      one decode_batch of the resident batch (inputs already in HBM, device I/O)
+  N > 1     trials are independent: each rank decodes its own 4096 trials (seed =
+            base + global trial index), no data-path collective; one RCCL all_gather
+            of the success flags after the timed region  -> "scaling": "weak"
+
+Also reported on the same JSON line:
+  roofline      dominant kernel (min-sum check-node update), algorithmic bytes per launch
+                (8 B per edge per codeword) / HIP-event launch duration vs 8 TB/s
+  cpu_baseline  the CPU oracle's f32 restatement (oracle/, a "port": the reference's own
+                decoder binaries cannot run here) on a bounded sample, host cores stated
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec (6.29 TB/s measured copy)
+
+WORKLOADS = {
+    # name: (hqc set, first-row key, method, max_iter)
+    "hqc128_minsum": ("hqc128", "N17669_W50_s0", "min_sum", 50),
+    "hqc192_minsum": ("hqc192", "N35851_W50_s0", "min_sum", 50),
+    "hqc256_tanh": ("hqc256", "N57637_W50_s0", "product_sum", 50),
+    "hqc128_tanh": ("hqc128", "N17669_W50_s0", "product_sum", 50),
+}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=4096)
+    ap.add_argument("--workload", default="hqc128_minsum", choices=sorted(WORKLOADS))
+    ap.add_argument("--eps", type=float, default=0.05)
+    ap.add_argument("--tile-group", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (no CPU fallback in the product path)")
+    torch.cuda.set_device(local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+
+    S = importlib.import_module("sca-ldpc_amd")
+    bp = importlib.import_module("sca-ldpc_amd.bp")
+    lib = importlib.import_module("sca-ldpc_amd._lib")
+    trials = importlib.import_module("sca-ldpc_amd.trials")
+    lib.check(lib.load().scaldpc_set_device(local))
+
+    hqc, key, method, iters = WORKLOADS[args.workload]
+    rows = json.load(open(os.path.join(ROOT, "tests", "golden", "hqc_first_rows.json")))
+    H, Hin, _ = S.codes.hqc_bench_graph(hqc, rows[key])
+    N, omega = S.codes.HQC_PARAMS[hqc]
+    R, E, n = Hin.m, H.nnz, H.n
+    batch = args.batch
+    probs = trials.hqc_priors(N, R, omega, args.eps)
+    msg, ys = trials.hqc_trials(Hin, omega, args.eps, batch, base_seed=2, first_index=rank * batch)
+
+    dec = bp.bp_decoder(H, max_iter=iters, bp_method=method, channel_probs=probs)
+    if args.tile_group:
+        dec.set_tile_group(args.tile_group)
+    dev = torch.device("cuda", local)
+    d_in = torch.from_numpy(msg).to(dev)
+    d_out = torch.empty((batch, n), dtype=torch.uint8, device=dev)
+    d_conv = torch.empty(batch, dtype=torch.uint8, device=dev)
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def step():
+        dec.decode_batch_device(d_in.data_ptr(), lib.IN_RECEIVED, batch, d_out.data_ptr(), early_exit=False,
+                                stream=stream, d_out_conv=d_conv.data_ptr())
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+
+    # per-kernel launch durations, HIP events on the launch stream
+    kt = dec.time_kernels(10, stream=stream)
+    ms_check = kt["ms_check"] / max(1, kt["launches_check"])
+    ms_var_pass = kt["ms_var"] / 10.0
+    swept = kt["codewords"]  # codewords per launch (tile padded)
+
+    # success statistics + the one end-of-run collective
+    ok = torch.from_numpy(trials.success(d_out.cpu().numpy(), ys, N).astype(np.uint8)).to(dev)
+    if world > 1:
+        allok = [torch.empty_like(ok) for _ in range(world)]
+        dist.all_gather(allok, ok)
+        ok_all = torch.cat(allok)
+    else:
+        ok_all = ok
+    succ = float(ok_all.float().mean().item())
+    conv = float(d_conv.float().mean().item())
+
+    if rank == 0:
+        total_cw = batch * world * args.steps
+        updates = 2.0 * E * iters * total_cw
+        value = updates / dt
+        algo_bytes_per_check_launch = 8.0 * E * swept  # 4 B read + 4 B written per edge per codeword
+        check_gbs = algo_bytes_per_check_launch / (ms_check * 1e-3) / 1e9
+        dominant_is_check = method == "min_sum"
+        out = {
+            "metric": "edge_message_updates_per_s",
+            "value": value,
+            "unit": "directed edge-message updates/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": f"{hqc} H=[Hin|I] N={N} W=50 R={R} E={E}, batch {batch}/GPU, {iters} fixed iters, {method}",
+                "batch_per_gpu": batch,
+                "iters": iters,
+                "eps": args.eps,
+                "tile_group": args.tile_group,
+            },
+            "codewords_per_s": total_cw / dt,
+            "whole_job_algorithmic_GBps": 16.0 * E * iters * total_cw / dt / 1e9,
+            "decode_success_rate": succ,
+            "converged_rate": conv,
+            "kernel_ms": {"check_per_launch": ms_check, "var_pass": ms_var_pass},
+        }
+        if dominant_is_check:
+            out["roofline"] = {
+                "bound": "hbm",
+                "kernel": "k_check_minsum",
+                "achieved": check_gbs,
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": check_gbs / HBM_PEAK_GBS,
+                "traffic": None,
+            }
+        else:
+            pass_gbs = 8.0 * E * swept / (kt["ms_check"] / 10.0 * 1e-3) / 1e9
+            out["roofline"] = {
+                "bound": "hbm",
+                "kernel": "k_check_tanh (all row buckets of one pass)",
+                "achieved": pass_gbs,
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": pass_gbs / HBM_PEAK_GBS,
+                "traffic": None,
+            }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(H, probs, msg, iters, method, E, args.cpu_seconds)
+        print(json.dumps(out), flush=True)
+    dec.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(H, probs, msg, iters, method, E, budget_s):
+    """The CPU oracle (f32 restatement, oracle/) on a bounded sample of the same workload,
+    all host threads over the batch.  A reported baseline -- NOT the reference binary
+    (ldpc==0.1.3 / simulate_rs cannot run here) and not the optimisation target."""
+    from oracle import pyoracle
+
+    om = {"min_sum": "min_sum", "product_sum": "product_sum_log"}[method]
+    threads = max(1, min(os.cpu_count() or 1, pyoracle.max_threads()))
+    t0 = time.perf_counter()
+    pyoracle.bp_decode_batch(H, probs, msg[:1], 1, iters, om, dtype="f32", threads=1, early_exit=False)
+    one = time.perf_counter() - t0
+    sample = int(max(threads, min(msg.shape[0], budget_s / max(one, 1e-6) * threads)))
+    sample = max(threads, (sample // threads) * threads)
+    sample = min(sample, msg.shape[0])
+    t0 = time.perf_counter()
+    pyoracle.bp_decode_batch(H, probs, msg[:sample], 1, iters, om, dtype="f32", threads=threads, early_exit=False)
+    dt = time.perf_counter() - t0
+    return {
+        "value": 2.0 * E * iters * sample / dt,
+        "unit": "directed edge-message updates/s",
+        "cores": threads,
+        "kind": "port",
+        "sample": f"first {sample} codewords of the same batch, {iters} fixed iterations, f32 {om}, "
+        f"{threads} OpenMP threads over codewords ({dt:.1f} s); restated CPU path, not the reference binary",
+        "codewords_per_s": sample / dt,
+    }
+
+
+if __name__ == "__main__":
+    main()

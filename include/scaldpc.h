@@ -1,0 +1,131 @@
+/*
+ * scaldpc.h -- C ABI of libscaldpc: MI355X (gfx950) LDPC belief-propagation
+ * decoders behind the decoder boundary of atneit/SCA-LDPC's Monte-Carlo drivers.
+ *
+ * Plain C types only (pointers, sizes, ints); opaque handles; every entry point
+ * returns an int status (0 = ok) and never throws across the boundary;
+ * scaldpc_last_error() gives the message of the calling thread's last failure.
+ *
+ * What each entry point replaces in the reference (paths relative to
+ * simulate-with-python/):
+ *
+ *   scaldpc_bp_create            ldpc.bp_decoder.__init__ dense->sparse graph build,
+ *                                call sites simulate/decode.py:155-161, simulate/hqc.py:694-699
+ *   scaldpc_bp_set_channel_probs the `error_rate=` / `channel_probs=` constructor kwargs (same sites)
+ *   scaldpc_bp_decode_batch      ldpc.bp_decoder.decode(v), simulate/decode.py:171, simulate/hqc.py:708
+ *                                (batched: one call = `batch` independent decode() calls)
+ *   scaldpc_bp_destroy           object lifetime
+ *   scaldpc_qary_create          simulate_rs Decoder::new via PyO3 `#[new]`,
+ *                                simulate_rs/src/pydecoder.rs:24-45 -> simulate_rs/src/decoder.rs:494-553
+ *   scaldpc_qary_min_sum_batch   PyO3 `min_sum`, simulate_rs/src/pydecoder.rs:53-65
+ *                                -> decoder.rs:668-692 (into_llr) + decoder.rs:560-666 (min_sum)
+ *   scaldpc_qary_special_create / _min_sum_batch
+ *                                simulate_rs/src/pydecoder.rs:96-117,125-145
+ *                                -> simulate_rs/src/decoder_special.rs:387-464, 471-617
+ *
+ * Threading: calls on distinct handles are independent; calls on one handle are
+ * serialised internally, so one decoder object may be shared by many host
+ * threads as the reference's thread pool does (simulate/decode.py:247-262).
+ *
+ * Device / host buffers: unless SCALDPC_F_DEVICE_IO is set, `in`/`out_*` are host
+ * pointers and are staged through device memory by the call.  With
+ * SCALDPC_F_DEVICE_IO they are device pointers (e.g. torch tensors' data_ptr())
+ * and nothing crosses PCIe.  `stream` is a hipStream_t passed as void* (NULL =
+ * the handle's own stream); the call returns after the stream work is complete
+ * unless SCALDPC_F_ASYNC is set (device I/O only).
+ */
+#ifndef SCALDPC_H
+#define SCALDPC_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SCALDPC_VERSION 100
+
+/* status codes */
+#define SCALDPC_OK 0
+#define SCALDPC_EINVAL 1   /* bad argument (shape, mode, method, NULL) -> Python ValueError */
+#define SCALDPC_EHIP 2     /* HIP runtime failure */
+#define SCALDPC_ENOMEM 3
+#define SCALDPC_EPMF 4     /* pmf row does not sum to 1 +- 1e-3 (decoder.rs:683-684 assert) */
+#define SCALDPC_ENOCONF 5  /* a check admits no finite configuration (decoder.rs:618 assert) */
+#define SCALDPC_EDEGREE 6  /* degree/alphabet outside what the kernels are built for */
+
+/* bp methods (ldpc.bp_decoder `bp_method`) */
+#define SCALDPC_BP_PRODUCT_SUM 0 /* "product_sum"/"ps"(+_log): tanh rule, LLR domain, fp32 */
+#define SCALDPC_BP_MIN_SUM 1     /* "min_sum"/"ms"(+_log): scaling `alpha` (0 => 1 - 2^-iter) */
+
+/* decode input convention (ldpc.bp_decoder.decode) */
+#define SCALDPC_IN_SYNDROME 0 /* in: uint8 [batch][m]; result = error estimate e */
+#define SCALDPC_IN_RECEIVED 1 /* in: uint8 [batch][n]; s = H v mod 2; result = e XOR v */
+
+/* flags */
+#define SCALDPC_F_EARLY_EXIT 1u /* per-codeword stop at H e == s (reference behaviour) */
+#define SCALDPC_F_DEVICE_IO 2u  /* in/out pointers are device pointers */
+#define SCALDPC_F_ASYNC 4u      /* with DEVICE_IO: enqueue only, caller synchronises `stream` */
+
+const char *scaldpc_last_error(void);
+int scaldpc_version(void);
+int scaldpc_device_count(int *count);
+int scaldpc_set_device(int device);
+
+/* ------------------------------------------------------------------ binary BP */
+typedef struct scaldpc_bp scaldpc_bp;
+
+/* Graph in CSR: row_ptr[m+1], col_idx[nnz] ascending inside each row (host pointers). */
+int scaldpc_bp_create(int32_t m, int32_t n, int64_t nnz, const int32_t *row_ptr,
+                      const int32_t *col_idx, scaldpc_bp **out);
+/* Per-bit prior error probabilities, float64 [n] (host). p = 0 / p = 1 are legal
+ * (LLR = +-inf), as the reference's certainty-1.0 checks produce (hqc.py:689). */
+int scaldpc_bp_set_channel_probs(scaldpc_bp *h, const double *probs);
+/*
+ * Decode `batch` independent inputs, flooding schedule, fp32 messages.
+ *   max_iter <= 0 -> n (ldpc convention)
+ *   out_bits  uint8 [batch][n]   required
+ *   out_llr   float [batch][n]   optional (NULL): posterior log(p0/p1) of the error estimate
+ *   out_iters int32 [batch]      optional: iteration at which H e == s first held (else max_iter)
+ *   out_conv  uint8 [batch]      optional: 1 iff the returned decision satisfies H e == s
+ */
+int scaldpc_bp_decode_batch(scaldpc_bp *h, const uint8_t *in, int32_t input_kind, int32_t batch,
+                            int32_t max_iter, int32_t method, float alpha, uint32_t flags,
+                            void *stream, uint8_t *out_bits, float *out_llr, int32_t *out_iters,
+                            uint8_t *out_conv);
+/*
+ * Measurement aid for bench.py: run `iters` iterations of `method` on the state
+ * left by the last decode (same batch), bracketing every kernel launch with HIP
+ * events on the launch stream.  ms[0] = total check-kernel ms, ms[1] = total
+ * variable-kernel ms, launches[0..1] = number of launches of each.
+ */
+int scaldpc_bp_time_kernels(scaldpc_bp *h, int32_t iters, int32_t method, float alpha, void *stream,
+                            float *ms, int32_t *launches);
+/* Tuning knob: codeword tiles (256 codewords each) iterated together; 0 = all. */
+int scaldpc_bp_set_tile_group(scaldpc_bp *h, int32_t tiles);
+void scaldpc_bp_destroy(scaldpc_bp *h);
+
+/* ------------------------------------------------------------ q-ary min-sum */
+typedef struct scaldpc_qary scaldpc_qary;
+
+/* H: int8 [R][N] dense row-major with entries in {-1,0,+1} (what pydecoder.rs:24
+ * receives), Q = 2B+1 symbols, `iterations` fixed (no early exit, decoder.rs:660). */
+int scaldpc_qary_create(int32_t R, int32_t N, int32_t B, const int8_t *H, int32_t iterations,
+                        scaldpc_qary **out);
+/* pmf: float [batch][N][Q] probabilities (LLR conversion inside, as pydecoder.rs:60);
+ * out: int8 [batch][N] hard decisions in [-B, B]. */
+int scaldpc_qary_min_sum_batch(scaldpc_qary *h, const float *pmf, int32_t batch, uint32_t flags,
+                               void *stream, int8_t *out);
+void scaldpc_qary_destroy(scaldpc_qary *h);
+
+/* DecoderSpecial: H = [H' | I_R]; first N-R variables over [-B,B], last R over [-BSUM,BSUM]. */
+int scaldpc_qary_special_create(int32_t R, int32_t N, int32_t B, int32_t BSUM, const int8_t *H,
+                                int32_t iterations, scaldpc_qary **out);
+/* pmf_b: float [batch][N-R][2B+1]; pmf_sum: float [batch][R][2BSUM+1]; out int8 [batch][N]. */
+int scaldpc_qary_special_min_sum_batch(scaldpc_qary *h, const float *pmf_b, const float *pmf_sum,
+                                       int32_t batch, uint32_t flags, void *stream, int8_t *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SCALDPC_H */

@@ -65,7 +65,7 @@
                                      const double *channel_probs, const uint8_t *in, int mode,     \
                                      int batch, int max_iter, int method, double alpha,            \
                                      uint8_t *out_bits, REAL *out_llr, int32_t *out_iter,          \
-                                     int32_t *out_conv, int threads)                               \
+                                     int32_t *out_conv, int threads, int early_exit)               \
     {                                                                                              \
         if (mode != 0 && mode != 1) return -2;                                                     \
         const int in_len = mode ? n : m;                                                           \
@@ -91,7 +91,7 @@
                 int r = oracle_bp_decode_##SFX(m, n, row_ptr, col_idx, col_ptr, csc_edge,          \
                                                channel_probs, synd, max_iter, method, alpha,       \
                                                out_bits + (size_t)b * n, out_llr + (size_t)b * n,  \
-                                               out_iter + b, out_conv + b, work);                  \
+                                               out_iter + b, out_conv + b, work, early_exit);      \
                 if (r) rc = r;                                                                     \
                 if (mode == 1)                                                                     \
                     for (int j = 0; j < n; j++) out_bits[(size_t)b * n + j] ^= v[j] & 1;           \

@@ -49,7 +49,7 @@ def max_threads():
 METHODS = {"product_sum": 0, "ps": 0, "min_sum": 1, "ms": 1, "min_sum_log": 1, "msl": 1, "product_sum_log": 2, "psl": 2}
 
 
-def bp_decode_batch(g, channel_probs, inputs, mode, max_iter, method, alpha=1.0, dtype="f64", threads=1):
+def bp_decode_batch(g, channel_probs, inputs, mode, max_iter, method, alpha=1.0, dtype="f64", threads=1, early_exit=True):
     """g: TannerGraph-like (m, n, row_ptr, col_idx, col_ptr, csc_edge).
     inputs: uint8 [batch, m] (mode 0, syndromes) or [batch, n] (mode 1, received).
     Returns dict(bits uint8 [batch,n], llr [batch,n], iters int32, converged int32)."""
@@ -76,7 +76,7 @@ def bp_decode_batch(g, channel_probs, inputs, mode, max_iter, method, alpha=1.0,
         _p(g.col_ptr, C.c_int32), _p(g.csc_edge, C.c_int32), _p(probs, C.c_double),
         _p(inputs, C.c_uint8), C.c_int(mode), C.c_int(batch), C.c_int(max_iter), C.c_int(m),
         C.c_double(alpha), _p(bits, C.c_uint8), _p(llr, ct), _p(iters, C.c_int32), _p(conv, C.c_int32),
-        C.c_int(threads),
+        C.c_int(threads), C.c_int(1 if early_exit else 0),
     )  # fmt: skip
     if rc:
         raise RuntimeError(f"oracle_bp_decode_batch failed: {rc}")

@@ -1,0 +1,216 @@
+"""`ldpc.bp_decoder`-shaped front end of the HIP binary BP decoder.
+
+Mirrors the constructor/`decode()` surface the reference uses
+(simulate/decode.py:155-161,171; simulate/hqc.py:694-699,708): same argument
+names and meaning, same error behaviour (ValueError on a bad method, a bad
+`channel_probs` length or a wrong-length input), same read-only result
+attributes (`bp_decoding`, `log_prob_ratios`, `converge`, `iter`).  On top of
+that: `decode_batch`, which decodes many independent inputs per call -- the
+Monte-Carlo drivers' trials are independent (decode.py:165), so the batch
+dimension is what feeds the GPU.
+
+Differences from the reference package, all deliberate:
+  * messages are fp32 (the package computes in float64);
+  * "product_sum" runs the tanh rule in the LLR domain (the package's ratio-domain
+    recursion is the same function of the messages);
+  * H may be a dense array (as the reference passes), a scipy sparse matrix or a
+    `TannerGraph`; it is never densified.
+There is no CPU fallback: constructing a decoder without libscaldpc.so raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from .graph import TannerGraph
+
+_PS = {"prod_sum", "product_sum", "ps", "0", "prod sum", "prod_sum_log", "product_sum_log", "ps_log", "2", "psl"}
+_MS = {"min_sum", "minimum_sum", "ms", "1", "minimum sum", "min sum", "min_sum_log", "minimum_sum_log", "ms_log", "3",
+       "minimum sum_log", "msl"}  # fmt: skip
+
+
+def _method_id(bp_method):
+    key = str(bp_method).lower()
+    if key in _PS:
+        return _lib.BP_PRODUCT_SUM
+    if key in _MS:
+        return _lib.BP_MIN_SUM
+    raise ValueError(
+        f"BP method '{bp_method}' is invalid. Please choose from the following methods: "
+        "'product_sum', 'minimum_sum', 'product_sum_log' or 'minimum_sum_log'"
+    )
+
+
+def _vector_type(t):
+    if t in (-1, "auto", None):
+        return -1
+    if t in (0, "syndrome"):
+        return _lib.IN_SYNDROME
+    if t in (1, "received_vector", "received"):
+        return _lib.IN_RECEIVED
+    raise ValueError(f"input_vector_type '{t}' is invalid. Choose 'syndrome', 'received_vector' or 'auto'.")
+
+
+class BpDecoder:
+    def __init__(
+        self,
+        parity_check_matrix,
+        error_rate=None,
+        max_iter=0,
+        bp_method=0,
+        ms_scaling_factor=1.0,
+        channel_probs=[None],
+        input_vector_type=-1,
+    ):
+        self._h = None
+        self._lib = _lib.load()  # raises when the HIP extension is missing
+        g = TannerGraph.coerce(parity_check_matrix)
+        self.graph = g
+        self.m, self.n = g.m, g.n
+        self.max_iter = int(max_iter) if int(max_iter) != 0 else self.n
+        if self.max_iter < 0:
+            raise ValueError("max_iter must be non-negative")
+        self._method = _method_id(bp_method)
+        self.bp_method = "product_sum" if self._method == _lib.BP_PRODUCT_SUM else "minimum_sum"
+        self.ms_scaling_factor = float(ms_scaling_factor)
+        self._vector_type = _vector_type(input_vector_type)
+        h = C.c_void_p()
+        _lib.check(
+            self._lib.scaldpc_bp_create(g.m, g.n, g.nnz, _lib.ptr(g.row_ptr), _lib.ptr(g.col_idx), C.byref(h))
+        )
+        self._h = h
+        # priors, as the package resolves them: channel_probs wins over error_rate
+        cp = list(channel_probs) if channel_probs is not None else [None]
+        if len(cp) and cp[0] is not None:
+            if len(cp) != self.n:
+                raise ValueError(
+                    f"The length of the channel probability vector must be eqaul to the block length n={self.n}."
+                )
+            probs = np.asarray(cp, dtype=np.float64)
+        elif error_rate is not None:
+            probs = np.full(self.n, float(error_rate), dtype=np.float64)
+        else:
+            raise ValueError(
+                "Please specify the error channel. Either: 1) error_rate: float or 2) channel_probs: list of floats "
+                "indicating the error probability on each bit. "
+            )
+        self.update_channel_probs(probs)
+        self.error_rate = error_rate
+        # result attributes of the last decode()
+        self.bp_decoding = np.zeros(self.n, dtype=int)
+        self.log_prob_ratios = np.zeros(self.n, dtype=np.float64)
+        self.converge = 0
+        self.iter = 0
+
+    # -- ldpc-compatible API --------------------------------------------------
+    def update_channel_probs(self, channel):
+        probs = np.ascontiguousarray(channel, dtype=np.float64)
+        if probs.shape != (self.n,):
+            raise ValueError(
+                f"The length of the channel probability vector must be eqaul to the block length n={self.n}."
+            )
+        _lib.check(self._lib.scaldpc_bp_set_channel_probs(self._h, _lib.ptr(probs)))
+        self.channel_probs = probs
+
+    def _resolve_kind(self, length, input_vector_type=None):
+        kind = self._vector_type if input_vector_type is None else _vector_type(input_vector_type)
+        if kind == -1:
+            if self.m == self.n:
+                raise ValueError(
+                    "parity check matrix is square: the input vector type is ambiguous, please set "
+                    "input_vector_type to 'syndrome' or 'received_vector'"
+                )
+            if length == self.m:
+                kind = _lib.IN_SYNDROME
+            elif length == self.n:
+                kind = _lib.IN_RECEIVED
+        want = self.m if kind == _lib.IN_SYNDROME else self.n if kind == _lib.IN_RECEIVED else None
+        if want is None or length != want:
+            raise ValueError(
+                f"The input to the ldpc.bp_decoder.decode must be either a received word (of length={self.n}) or a "
+                f"syndrome (of length={self.m}). The inputted vector has length={length}. Valid formats are "
+                "`np.ndarray` or `scipy.sparse.spmatrix`."
+            )
+        return kind
+
+    def decode(self, input_vector):
+        """One decode, reference semantics (early exit at H e == s).  Returns int array [n]."""
+        v = np.asarray(input_vector)
+        if v.ndim != 1:
+            v = v.reshape(-1)
+        r = self.decode_batch(v[None, :], want_llr=True)
+        self.bp_decoding = r["bits"][0].astype(int)
+        self.log_prob_ratios = r["llr"][0].astype(np.float64)
+        self.converge = int(r["converged"][0])
+        self.iter = int(r["iters"][0])
+        return self.bp_decoding
+
+    # -- batched API ------------------------------------------------------------
+    def decode_batch(self, inputs, max_iter=None, early_exit=True, want_llr=False, input_vector_type=None):
+        """inputs: [batch, m] syndromes or [batch, n] received words (any integer dtype).
+        Returns dict(bits uint8 [batch, n], llr float32 [batch, n] or None,
+        iters int32 [batch], converged uint8 [batch])."""
+        x = np.asarray(inputs)
+        if x.ndim != 2:
+            raise ValueError("decode_batch expects a 2-D array [batch, length]")
+        kind = self._resolve_kind(x.shape[1], input_vector_type)
+        x = np.ascontiguousarray(x & 1 if x.dtype != np.uint8 else x, dtype=np.uint8)
+        batch = x.shape[0]
+        if batch == 0:
+            raise ValueError("empty batch")
+        bits = np.empty((batch, self.n), dtype=np.uint8)
+        llr = np.empty((batch, self.n), dtype=np.float32) if want_llr else None
+        iters = np.empty(batch, dtype=np.int32)
+        conv = np.empty(batch, dtype=np.uint8)
+        flags = _lib.F_EARLY_EXIT if early_exit else 0
+        _lib.check(
+            self._lib.scaldpc_bp_decode_batch(
+                self._h, _lib.ptr(x), kind, batch, self.max_iter if max_iter is None else int(max_iter),
+                self._method, self.ms_scaling_factor, flags, None, _lib.ptr(bits), _lib.ptr(llr),
+                _lib.ptr(iters), _lib.ptr(conv),
+            )  # fmt: skip
+        )
+        return {"bits": bits, "llr": llr, "iters": iters, "converged": conv}
+
+    def decode_batch_device(self, d_in, kind, batch, d_out_bits, max_iter=None, early_exit=False, stream=0,
+                            d_out_llr=0, d_out_iters=0, d_out_conv=0, asynchronous=False):
+        """Device-pointer variant (ints, e.g. torch `tensor.data_ptr()`): nothing crosses PCIe."""
+        flags = _lib.F_DEVICE_IO | (_lib.F_EARLY_EXIT if early_exit else 0) | (_lib.F_ASYNC if asynchronous else 0)
+        _lib.check(
+            self._lib.scaldpc_bp_decode_batch(
+                self._h, C.c_void_p(d_in), kind, batch, self.max_iter if max_iter is None else int(max_iter),
+                self._method, self.ms_scaling_factor, flags, C.c_void_p(stream or None), C.c_void_p(d_out_bits),
+                C.c_void_p(d_out_llr or None), C.c_void_p(d_out_iters or None), C.c_void_p(d_out_conv or None),
+            )  # fmt: skip
+        )
+
+    def time_kernels(self, iters, stream=0):
+        """HIP-event timing of the check / variable kernels on the last decode's state.
+        Returns dict(ms_check, ms_var, launches_check, launches_var, codewords)."""
+        ms = (C.c_float * 2)()
+        ln = (C.c_int32 * 3)()
+        _lib.check(
+            self._lib.scaldpc_bp_time_kernels(
+                self._h, iters, self._method, self.ms_scaling_factor, C.c_void_p(stream or None), ms, ln
+            )
+        )
+        return {"ms_check": ms[0], "ms_var": ms[1], "launches_check": ln[0], "launches_var": ln[1], "codewords": ln[2]}
+
+    def set_tile_group(self, tiles):
+        _lib.check(self._lib.scaldpc_bp_set_tile_group(self._h, int(tiles)))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.scaldpc_bp_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+bp_decoder = BpDecoder

@@ -1,0 +1,56 @@
+"""Shared builders for the parity tests (seeded inputs, HQC-shaped instances)."""
+import importlib
+
+import numpy as np
+
+S = importlib.import_module("sca-ldpc_amd")
+
+
+def random_graph(rng, m, n, density, ensure_cover=True):
+    H = (rng.rand(m, n) < density).astype(np.int8)
+    if ensure_cover:
+        for i in range(m):
+            if not H[i].any():
+                H[i, rng.randint(n)] = 1
+    return S.TannerGraph.from_dense(H)
+
+
+def hqc_instance(N, W, R, omega, eps, batch, seed, flip=True):
+    """[Hin | I_R] with synthetic trials as SURVEY.md 8(d) defines them: y = omega
+    distinct positions, checks = Hin y (+ flips with prob eps), priors
+    [omega/N]*N ++ [eps]*R, message [0]*N ++ checks (hqc.py:684-705)."""
+    rng = np.random.RandomState(seed)
+    sup = S.codes.make_random_ldpc_first_row(N, W, rng)
+    rows = rng.permutation(N)[:R]
+    Hin = S.codes.hqc_check_graph(sup, N, rows)
+    H = Hin.with_identity()
+    y = np.zeros((batch, N), dtype=np.uint8)
+    for b in range(batch):
+        y[b, rng.choice(N, omega, replace=False)] = 1
+    checks = Hin.syndrome(y)
+    if flip and eps > 0:
+        checks = checks ^ (rng.rand(batch, R) < eps).astype(np.uint8)
+    msg = np.concatenate([np.zeros((batch, N), dtype=np.uint8), checks], axis=1)
+    probs = np.concatenate([np.full(N, omega / N), np.full(R, eps)])
+    return H, Hin, probs, msg, y
+
+
+ORACLE_METHOD = {"min_sum": "min_sum", "product_sum": "product_sum_log"}
+
+
+def compare(got, ref, method, llr_rtol=2e-3, llr_atol=2e-3):
+    """HIP result vs f32 oracle.  Integer outputs bit-exact always; min-sum posteriors
+    bit-exact (only add/compare/abs, same order); tanh-rule posteriors within the
+    stated fp32 tolerance |dL| <= atol + rtol*|L| wherever the oracle's L is finite
+    (device tanhf/logf differ from glibc's by ulps)."""
+    assert np.array_equal(got["iters"], ref["iters"]), "iteration counts differ"
+    assert np.array_equal(got["converged"].astype(np.int32), ref["converged"]), "converged flags differ"
+    assert np.array_equal(got["bits"], ref["bits"]), "hard decisions differ"
+    if got.get("llr") is not None:
+        if method == "min_sum":
+            assert np.array_equal(got["llr"], ref["llr"]), "min-sum posteriors must be bit-exact"
+        else:
+            fin = np.isfinite(ref["llr"])
+            assert np.array_equal(np.isfinite(got["llr"]), fin)
+            assert np.allclose(got["llr"][fin], ref["llr"][fin], rtol=llr_rtol, atol=llr_atol)
+            assert np.array_equal(got["llr"][~fin], ref["llr"][~fin])
