@@ -198,7 +198,7 @@ def cpu_baseline(H, probs, msg, iters, method, E, budget_s):
     (ldpc==0.1.3 / simulate_rs cannot run here) and not the optimisation target."""
     from oracle import pyoracle
 
-    om = {"min_sum": "min_sum", "product_sum": "product_sum_log"}[method]
+    om = {"min_sum": "min_sum", "product_sum": "tanh_complement"}[method]
     threads = max(1, min(os.cpu_count() or 1, pyoracle.max_threads()))
     t0 = time.perf_counter()
     pyoracle.bp_decode_batch(H, probs, msg[:1], 1, iters, om, dtype="f32", threads=1, early_exit=False)

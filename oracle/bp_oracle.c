@@ -26,6 +26,7 @@
 #define REAL double
 #define SFX f64
 #define RLOG log
+#define REXP exp
 #define RTANH tanh
 #define RABS fabs
 #define RBIG 1e308
@@ -33,6 +34,7 @@
 #undef REAL
 #undef SFX
 #undef RLOG
+#undef REXP
 #undef RTANH
 #undef RABS
 #undef RBIG
@@ -40,6 +42,7 @@
 #define REAL float
 #define SFX f32
 #define RLOG logf
+#define REXP expf
 #define RTANH tanhf
 #define RABS fabsf
 #define RBIG FLT_MAX
@@ -47,6 +50,7 @@
 #undef REAL
 #undef SFX
 #undef RLOG
+#undef REXP
 #undef RTANH
 #undef RABS
 #undef RBIG

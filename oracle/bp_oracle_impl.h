@@ -18,7 +18,12 @@
  *                                always selects): r = p/(1-p)
  *   method 1  "min_sum"(_log)    LLR domain, running two-sided min, sign count
  *                                where a message <= 0 counts as negative
- *   method 2  "product_sum_log"  LLR domain tanh rule
+ *   method 2  "product_sum_log"  LLR domain tanh rule, textbook form
+ *   method 3  the tanh rule in COMPLEMENT form -- the build's fp32 kernel order:
+ *             u_k = 1 - tanh(|x_k|/2) = 2/(exp|x_k| + 1); exclusive products kept as
+ *             U = 1 - prod(1-u) through U' = U + u(1-U); |c2v| = log(2/U - 1).
+ *             Same function as methods 0/2, but free of the 1-x cancellation that
+ *             makes the textbook form saturate at |L| ~ 17 in fp32.
  *
  * Parity status: pinned for HARD DECISIONS by the reference's three doctests
  * (decode.py:139-149; hqc.py:1229-1274; hqc.py:1277-1311) -- see
@@ -42,7 +47,8 @@ int FN(oracle_bp_decode)(int m, int n, const int32_t *row_ptr, const int32_t *co
     REAL *b2c = work;        /* bit_to_check   */
     REAL *c2b = work + nnz;  /* check_to_bit   */
     int *esgn = (int *)malloc(sizeof(int) * (size_t)(nnz > 0 ? nnz : 1));
-    if (!esgn) return -1;
+    REAL *ubuf = (REAL *)malloc(sizeof(REAL) * (size_t)(nnz > 0 ? nnz : 1));
+    if (!esgn || !ubuf) return -1;
     if (max_iter <= 0) max_iter = n;
 
     /* initial bit-to-check messages */
@@ -84,6 +90,29 @@ int FN(oracle_bp_decode)(int m, int n, const int32_t *row_ptr, const int32_t *co
                     c2b[e] *= temp;
                     c2b[e] = sg * RLOG(((REAL)1 + c2b[e]) / ((REAL)1 - c2b[e]));
                     temp *= RTANH(b2c[e] / (REAL)2);
+                }
+            }
+        } else if (method == 3) {
+            for (int i = 0; i < m; i++) {
+                REAL U = (REAL)0;
+                int sgn = synd[i] ? 1 : 0;
+                for (int e = row_ptr[i]; e < row_ptr[i + 1]; e++) {
+                    c2b[e] = U;
+                    esgn[e] = sgn;
+                    const REAL u = (REAL)2 / (REXP(RABS(b2c[e])) + (REAL)1);
+                    ubuf[e] = u;
+                    U = U + u * ((REAL)1 - U);
+                    if (b2c[e] < (REAL)0) sgn += 1;
+                }
+                U = (REAL)0;
+                sgn = 0;
+                for (int e = row_ptr[i + 1] - 1; e >= row_ptr[i]; e--) {
+                    const REAL Ut = c2b[e] + U * ((REAL)1 - c2b[e]);
+                    esgn[e] += sgn;
+                    const REAL Lm = RLOG((REAL)2 / Ut - (REAL)1);
+                    c2b[e] = (esgn[e] & 1) ? -Lm : Lm;
+                    U = U + ubuf[e] * ((REAL)1 - U);
+                    if (b2c[e] < (REAL)0) sgn += 1;
                 }
             }
         } else { /* min-sum */
@@ -167,6 +196,7 @@ int FN(oracle_bp_decode)(int m, int n, const int32_t *row_ptr, const int32_t *co
         if (ok && early_exit) break;
     }
     free(esgn);
+    free(ubuf);
     return 0;
 }
 

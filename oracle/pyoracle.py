@@ -46,7 +46,8 @@ def max_threads():
     return int(lib().oracle_max_threads())
 
 
-METHODS = {"product_sum": 0, "ps": 0, "min_sum": 1, "ms": 1, "min_sum_log": 1, "msl": 1, "product_sum_log": 2, "psl": 2}
+METHODS = {"product_sum": 0, "ps": 0, "min_sum": 1, "ms": 1, "min_sum_log": 1, "msl": 1, "product_sum_log": 2, "psl": 2,
+           "tanh_complement": 3}
 
 
 def bp_decode_batch(g, channel_probs, inputs, mode, max_iter, method, alpha=1.0, dtype="f64", threads=1, early_exit=True):

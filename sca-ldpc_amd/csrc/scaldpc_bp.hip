@@ -312,11 +312,17 @@ __global__ __launch_bounds__(256) void k_check_minsum(const int *__restrict__ ro
 }
 
 // ---------------------------------------------------------------------------
-// K2  tanh-rule (sum-product) check-node update, LLR domain, fp32.
-//   forward : pre_k = prod_{k'<k} tanh(v2c_k'/2)
-//   backward: c2v_k = (-1)^s * log((1 + pre_k*suf_k) / (1 - pre_k*suf_k))
-// Row values live in registers (compile-time unrolled to MAXDEG, predicated on the
-// wave-uniform degree).  wave = (row, quarter tile): lane handles 1 codeword.
+// K2  tanh-rule (sum-product) check-node update, LLR domain, fp32, COMPLEMENT form.
+//   c2v_k = (-1)^(s + #{k' != k : x_k' < 0}) * 2 atanh( prod_{k' != k} tanh(|x_k'|/2) )
+// computed without the 1-x cancellation that saturates the textbook form at |L|~17
+// in fp32:   u_k = 1 - tanh(|x_k|/2) = 2 / (exp|x_k| + 1)
+//            U   = 1 - prod(1 - u)   via  U' = U + u (1 - U)     (forward and backward)
+//            |c2v_k| = log(2 / U_excl - 1),  U_excl = Upre + Usuf (1 - Upre)
+// Exact for |L| up to ~88 (then u underflows to 0 and L = +inf, which is also what
+// p = 0 priors feed in).  Same exclusive forward/backward sweep as the reference
+// package; the CPU oracle's method 3 is this sequence op for op.
+// Row values live in registers (compile-time unrolled to MAXDEG <= 64, predicated on
+// the wave-uniform degree), signs in a 64-bit mask.  wave = (row, quarter tile).
 // grid (rows in bucket, G), block 256 = the 4 quarters of one (row, tile).
 // ---------------------------------------------------------------------------
 template <int MAXDEG>
@@ -330,31 +336,36 @@ __global__ __launch_bounds__(256) void k_check_tanh(const int *__restrict__ list
     const int e0 = rfl(row_ptr[r]);
     const int deg = rfl(row_ptr[r + 1]) - e0;
     const size_t base = ((size_t)tl * E + e0) * TW + q * 64 + lane;
-    float tt[MAXDEG], pre[MAXDEG];
+    float uu[MAXDEG], pre[MAXDEG];
 #pragma unroll
     for (int k = 0; k < MAXDEG; k++)
-        if (k < deg) tt[k] = v2c[base + (size_t)k * TW];
-    float temp = 1.0f;
+        if (k < deg) uu[k] = v2c[base + (size_t)k * TW];
+    u64 neg = 0;
+    float U = 0.0f;
 #pragma unroll
     for (int k = 0; k < MAXDEG; k++)
         if (k < deg) {
-            tt[k] = tanhf(tt[k] * 0.5f);
-            pre[k] = temp;
-            temp *= tt[k];
+            const float x = uu[k];
+            neg |= (u64)(x < 0.0f) << k;
+            const float u = 2.0f / (expf(fabsf(x)) + 1.0f);
+            uu[k] = u;
+            pre[k] = U;
+            U = U + u * (1.0f - U);
         }
-    const float sg = ((synd[((size_t)tl * m + r) * 4 + q] >> lane) & 1) ? -1.0f : 1.0f;
-    temp = 1.0f;
+    const unsigned tot = ((unsigned)__popcll(neg) ^ (unsigned)(synd[((size_t)tl * m + r) * 4 + q] >> lane)) & 1u;
+    U = 0.0f;
 #pragma unroll
     for (int k = MAXDEG - 1; k >= 0; k--)
         if (k < deg) {
-            const float x = pre[k] * temp;
-            c2v[base + (size_t)k * TW] = sg * logf((1.0f + x) / (1.0f - x));
-            temp *= tt[k];
+            const float Ut = pre[k] + U * (1.0f - pre[k]);
+            const float Lm = logf(2.0f / Ut - 1.0f);
+            c2v[base + (size_t)k * TW] = ((tot ^ (unsigned)(neg >> k)) & 1u) ? -Lm : Lm;
+            U = U + uu[k] * (1.0f - U);
         }
 }
 
-// Any-degree fallback: the forward sweep parks the prefix products in c2v itself
-// (exactly what the reference package does), the backward sweep re-reads v2c.
+// Any-degree fallback: the forward sweep parks Upre in c2v itself (as the reference
+// package parks its prefix products), the backward sweep re-reads v2c and recomputes u.
 // grid (rows in list, G), block 256.
 __global__ __launch_bounds__(256) void k_check_tanh_generic(const int *__restrict__ list,
                                                             const int *__restrict__ row_ptr,
@@ -367,17 +378,24 @@ __global__ __launch_bounds__(256) void k_check_tanh_generic(const int *__restric
     const int e0 = rfl(row_ptr[r]);
     const int deg = rfl(row_ptr[r + 1]) - e0;
     const size_t base = ((size_t)tl * E + e0) * TW + q * 64 + lane;
-    float temp = 1.0f;
+    float U = 0.0f;
+    unsigned par = (unsigned)(synd[((size_t)tl * m + r) * 4 + q] >> lane) & 1u;
     for (int k = 0; k < deg; k++) {
-        c2v[base + (size_t)k * TW] = temp;
-        temp *= tanhf(v2c[base + (size_t)k * TW] * 0.5f);
+        const float x = v2c[base + (size_t)k * TW];
+        c2v[base + (size_t)k * TW] = U;
+        par ^= (unsigned)(x < 0.0f);
+        const float u = 2.0f / (expf(fabsf(x)) + 1.0f);
+        U = U + u * (1.0f - U);
     }
-    const float sg = ((synd[((size_t)tl * m + r) * 4 + q] >> lane) & 1) ? -1.0f : 1.0f;
-    temp = 1.0f;
+    U = 0.0f;
     for (int k = deg - 1; k >= 0; k--) {
-        const float x = c2v[base + (size_t)k * TW] * temp;
-        c2v[base + (size_t)k * TW] = sg * logf((1.0f + x) / (1.0f - x));
-        temp *= tanhf(v2c[base + (size_t)k * TW] * 0.5f);
+        const float x = v2c[base + (size_t)k * TW];
+        const float p = c2v[base + (size_t)k * TW];
+        const float Ut = p + U * (1.0f - p);
+        const float Lm = logf(2.0f / Ut - 1.0f);
+        c2v[base + (size_t)k * TW] = ((par ^ (unsigned)(x < 0.0f)) & 1u) ? -Lm : Lm;
+        const float u = 2.0f / (expf(fabsf(x)) + 1.0f);
+        U = U + u * (1.0f - U);
     }
 }
 
