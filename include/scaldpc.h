@@ -101,7 +101,8 @@ int scaldpc_bp_decode_batch(scaldpc_bp *h, const uint8_t *in, int32_t input_kind
  */
 int scaldpc_bp_time_kernels(scaldpc_bp *h, int32_t iters, int32_t method, float alpha, void *stream,
                             float *ms, int32_t *launches);
-/* Tuning knob: codeword tiles (256 codewords each) iterated together; 0 = all. */
+/* Tuning knob: codeword tiles (64 codewords each) per cache-resident group; 0 = auto
+ * (largest group whose in-place message array stays within ~200 MB of Infinity Cache). */
 int scaldpc_bp_set_tile_group(scaldpc_bp *h, int32_t tiles);
 void scaldpc_bp_destroy(scaldpc_bp *h);
 

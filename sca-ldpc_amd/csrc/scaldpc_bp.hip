@@ -9,21 +9,31 @@
 // H e == s.  Nothing is ever "total minus self", so +-inf priors (certainty-1.0
 // checks, hqc.py:689) never meet an inf - inf.
 //
-// HBM layout (all fp32 messages; TW = 256 codewords form one tile):
-//     v2c, c2v : float [tile][edge][256]     edge id = CSR position
-//   A check node's edges are one contiguous range, so a wave working on
-//   (row, tile) streams deg x 1 KiB of consecutive memory with 16 B per lane;
-//   a variable node gathers its 1 KiB edge rows through the CSC permutation.
-//   Bit planes (syndrome, received word, hard decision, done mask):
-//     u64 [tile][node][4]    bit c of the 256-bit vector = codeword c of the tile
-//   posterior : float [tile][var][256]
+// Memory design (measured on MI355X, profiles/microbench/rmw_stream.hip):
+//   * ONE fp32 message array, updated IN PLACE: a check node reads all its v2c
+//     and then overwrites them with c2v at the same addresses; a variable node
+//     does the converse.  Every node owns its edges exclusively, so no other
+//     thread ever sees a half-updated edge.
+//         msg : float [tile][edge][64]      edge id = CSR position, tile = 64 codewords
+//     A check node's edges are one contiguous range: a wave working on
+//     (row, tile) streams deg x 256 B of consecutive memory; a variable node
+//     gathers its 256 B edge rows through the CSC permutation.
+//   * Codeword tiles are decoded in GROUPS whose message array fits the 256 MiB
+//     Infinity Cache (~<= 200 MB): all max_iter iterations of a group run
+//     back-to-back, so after the first touch the messages never go to HBM again
+//     (an in-place read-all/write-all stream runs at ~6.5-7.3 TB/s from the
+//     Infinity Cache against ~4.5 TB/s from HBM).
+//   * Bit planes (syndrome, received word, hard decision, done mask):
+//         u64 [tile][node]      bit c = codeword c of the tile
+//     posterior : float [tile][var][64]
 //
-// No MFMA anywhere: this is a sparse gather/scatter stream bound by HBM.
+// No MFMA anywhere: this is a sparse gather/scatter stream, not a contraction.
 #include "scaldpc_common.h"
 
 #include <algorithm>
 #include <cfloat>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <vector>
@@ -52,267 +62,226 @@ using namespace scaldpc;
 
 namespace {
 
-constexpr int TW = 256;  // codewords per tile
+constexpr int TW = 64;       // codewords per tile = one wavefront of lanes
+constexpr int MAXB = 8;      // degree buckets per node kind
+constexpr int ROW_CAP = 64;  // largest register-resident row degree (also the sign-mask width)
 
 __device__ __forceinline__ int rfl(int x) { return __builtin_amdgcn_readfirstlane(x); }
 
-// bits of the low 32 -> even bit positions of a 64-bit word
-__device__ __forceinline__ u64 spread32(u64 x)
-{
-    x &= 0xffffffffull;
-    x = (x | (x << 16)) & 0x0000ffff0000ffffull;
-    x = (x | (x << 8)) & 0x00ff00ff00ff00ffull;
-    x = (x | (x << 4)) & 0x0f0f0f0f0f0f0f0full;
-    x = (x | (x << 2)) & 0x3333333333333333ull;
-    x = (x | (x << 1)) & 0x5555555555555555ull;
-    return x;
-}
+// Degree buckets of one fused launch: blocks [blk[b], blk[b+1]) work on the nodes
+// list[off[b] .. off[b]+cnt[b]) with unroll bound maxd[b] (0 = any-degree fallback).
+struct Buckets {
+    int nb;
+    int maxd[MAXB];
+    int off[MAXB];
+    int cnt[MAXB];
+    int blk[MAXB + 1];
+};
 
 // ---------------------------------------------------------------------------
 // input / output reshaping
 // ---------------------------------------------------------------------------
-// uint8 [batch][len] (one row per codeword, as decode() receives them) ->
-// bit planes [tile][x][4].  grid (len, T), block 256: thread c = codeword c of the tile.
+// uint8 [batch][len] (one row per codeword, as decode() receives them) -> planes [tile][x].
+// wave = (tile, 16 consecutive x): lane c walks one 16-byte stretch of codeword c.
+// grid (ceil(len/64), T), block 256.
 __global__ __launch_bounds__(256) void k_pack_bits(const uint8_t *__restrict__ in, int len, int batch,
                                                    u64 *__restrict__ out)
 {
-    const int x = blockIdx.x, t = blockIdx.y, c = threadIdx.x;
-    const long b = (long)t * TW + c;
-    int bit = 0;
-    if (b < batch) bit = in[(size_t)b * len + x] & 1;
-    const u64 w = __ballot(bit);
-    if ((c & 63) == 0) out[((size_t)t * len + x) * 4 + (c >> 6)] = w;
+    const int lane = threadIdx.x & 63;
+    const int x0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 16;
+    const int t = blockIdx.y;
+    if (x0 >= len) return;
+    const long b = (long)t * TW + lane;
+    const uint8_t *p = in + (size_t)(b < batch ? b : 0) * len + x0;
+    const int nx = min(16, len - x0);
+    for (int j = 0; j < nx; j++) {
+        const int bit = (b < batch) ? (p[j] & 1) : 0;
+        const u64 w = __ballot(bit);
+        if (lane == 0) out[(size_t)t * len + x0 + j] = w;
+    }
 }
 
 // hard decision planes (XOR received planes) -> uint8 [batch][n].
-// grid (ceil(n/256), batch), block 256: consecutive threads = consecutive variables.
+// grid (ceil(n/256), T), block 256: a thread owns one variable of one tile.
 __global__ __launch_bounds__(256) void k_unpack_bits(const u64 *__restrict__ hard, const u64 *__restrict__ recv,
-                                                     int n, uint8_t *__restrict__ out)
+                                                     int n, int batch, uint8_t *__restrict__ out)
 {
     const int v = blockIdx.x * 256 + threadIdx.x;
-    const int b = blockIdx.y;
+    const int t = blockIdx.y;
     if (v >= n) return;
-    const int t = b >> 8, c = b & 255;
-    const size_t i = ((size_t)t * n + v) * 4 + (c >> 6);
-    u64 w = hard[i];
-    if (recv) w ^= recv[i];
-    out[(size_t)b * n + v] = (uint8_t)((w >> (c & 63)) & 1);
+    u64 w = hard[(size_t)t * n + v];
+    if (recv) w ^= recv[(size_t)t * n + v];
+    const int nb = min(TW, batch - t * TW);
+    for (int c = 0; c < nb; c++) out[(size_t)(t * TW + c) * n + v] = (uint8_t)((w >> c) & 1);
 }
 
-// posterior [tile][var][256] -> float [batch][n] via a 32x32 LDS transpose.
-// grid (ceil(n/32), 8, T), block (32, 8).
-__global__ void k_unpack_llr(const float *__restrict__ post, int n, int batch, float *__restrict__ out)
+// posterior [tile][var][64] -> float [batch][n] via an LDS transpose of 64 vars x 64 codewords.
+// grid (ceil(n/64), T), block 256.
+__global__ __launch_bounds__(256) void k_unpack_llr(const float *__restrict__ post, int n, int batch,
+                                                    float *__restrict__ out)
 {
-    __shared__ float tile[32][33];
-    const int t = blockIdx.z;
-    const int v0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
-    for (int j = threadIdx.y; j < 32; j += 8) {
-        const int v = v0 + j;
-        if (v < n) tile[j][threadIdx.x] = post[((size_t)t * n + v) * TW + c0 + threadIdx.x];
-    }
+    __shared__ float tile[64][65];
+    const int t = blockIdx.y, v0 = blockIdx.x * 64;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    for (int j = w; j < 64; j += 4)
+        if (v0 + j < n) tile[j][lane] = post[((size_t)t * n + v0 + j) * TW + lane];
     __syncthreads();
-    for (int j = threadIdx.y; j < 32; j += 8) {
-        const long b = (long)t * TW + c0 + j;
-        const int v = v0 + threadIdx.x;
-        if (b < batch && v < n) out[(size_t)b * n + v] = tile[threadIdx.x][j];
+    for (int c = w; c < 64; c += 4) {
+        const long b = (long)t * TW + c;
+        if (b < batch && v0 + lane < n) out[(size_t)b * n + v0 + lane] = tile[lane][c];
     }
 }
 
-// done planes + iteration counters -> int32 iters[batch], uint8 conv[batch]
-__global__ __launch_bounds__(256) void k_unpack_state(const u64 *__restrict__ conv_bits, const int *__restrict__ iters,
-                                                      int batch, int *__restrict__ out_iters,
-                                                      uint8_t *__restrict__ out_conv)
+// conv planes + iteration counters -> int32 iters[batch], uint8 conv[batch].  grid T, block 64.
+__global__ __launch_bounds__(64) void k_unpack_state(const u64 *__restrict__ conv_bits, const int *__restrict__ iters,
+                                                     int batch, int *__restrict__ out_iters,
+                                                     uint8_t *__restrict__ out_conv)
 {
     const int t = blockIdx.x, c = threadIdx.x;
     const long b = (long)t * TW + c;
     if (b >= batch) return;
     if (out_iters) out_iters[b] = iters[b];
-    if (out_conv) out_conv[b] = (uint8_t)((conv_bits[(size_t)t * 4 + (c >> 6)] >> (c & 63)) & 1);
+    if (out_conv) out_conv[b] = (uint8_t)((conv_bits[t] >> c) & 1);
 }
 
 // ---------------------------------------------------------------------------
 // parity of bit planes along the rows of H.  One thread per (row, tile).
 //   CHECK = false: synd[t][r] = XOR_v bits[t][v]          (received-vector mode: s = H v)
 //   CHECK = true : unsat[t] |= synd[t][r] ^ XOR_v bits    (convergence test H e == s)
-// The planes of one tile are n x 32 B (693 KB at HQC-128): L2 resident.
+// The planes of one tile are n x 8 B (173 KB at HQC-128): L2 resident.
 // grid (ceil(m/256), T), block 256.
 // ---------------------------------------------------------------------------
 template <bool CHECK>
 __global__ __launch_bounds__(256) void k_parity(const int *__restrict__ row_ptr, const int *__restrict__ col_idx,
                                                 const u64 *__restrict__ bits, int m, int n, u64 *__restrict__ synd,
-                                                u64 *__restrict__ unsat)
+                                                u64 *__restrict__ unsat, const u64 *__restrict__ done)
 {
     const int r = blockIdx.x * 256 + threadIdx.x;
     const int t = blockIdx.y;
-    u64 a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+    if (CHECK && done[t] == ~0ull) return;  // whole tile frozen
+    u64 a = 0;
     if (r < m) {
         const int e1 = row_ptr[r + 1];
-        for (int e = row_ptr[r]; e < e1; e++) {
-            const ulonglong2 *p = (const ulonglong2 *)(bits + ((size_t)t * n + col_idx[e]) * 4);
-            const ulonglong2 lo = p[0], hi = p[1];
-            a0 ^= lo.x; a1 ^= lo.y; a2 ^= hi.x; a3 ^= hi.y;
-        }
-        u64 *s = synd + ((size_t)t * m + r) * 4;
-        if (CHECK) {
-            a0 ^= s[0]; a1 ^= s[1]; a2 ^= s[2]; a3 ^= s[3];
-        } else {
-            s[0] = a0; s[1] = a1; s[2] = a2; s[3] = a3;
-        }
+        for (int e = row_ptr[r]; e < e1; e++) a ^= bits[(size_t)t * n + col_idx[e]];
+        if (CHECK)
+            a ^= synd[(size_t)t * m + r];
+        else
+            synd[(size_t)t * m + r] = a;
     }
     if (CHECK) {
 #pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) {
-            a0 |= __shfl_xor(a0, off);
-            a1 |= __shfl_xor(a1, off);
-            a2 |= __shfl_xor(a2, off);
-            a3 |= __shfl_xor(a3, off);
-        }
-        if ((threadIdx.x & 63) == 0) {
-            u64 *u = unsat + (size_t)t * 4;
-            if (a0) atomicOr(u + 0, a0);
-            if (a1) atomicOr(u + 1, a1);
-            if (a2) atomicOr(u + 2, a2);
-            if (a3) atomicOr(u + 3, a3);
-        }
+        for (int off = 32; off >= 1; off >>= 1) a |= __shfl_xor(a, off);
+        if ((threadIdx.x & 63) == 0 && a) atomicOr(unsat + t, a);
     }
 }
 
-// per-tile state reset.  grid T, block 256.
-__global__ __launch_bounds__(256) void k_init_state(int batch, int max_iter, u64 *__restrict__ done,
-                                                    u64 *__restrict__ conv, u64 *__restrict__ unsat,
-                                                    int *__restrict__ iters)
+// per-tile state reset.  grid T, block 64.
+__global__ __launch_bounds__(64) void k_init_state(int batch, int max_iter, u64 *__restrict__ done,
+                                                   u64 *__restrict__ conv, u64 *__restrict__ unsat,
+                                                   int *__restrict__ iters)
 {
     const int t = blockIdx.x, c = threadIdx.x;
     const long b = (long)t * TW + c;
     iters[b] = max_iter;
     const u64 pad = __ballot(b >= batch);  // padding codewords are born "done"
-    if ((c & 63) == 0) {
-        done[(size_t)t * 4 + (c >> 6)] = pad;
-        conv[(size_t)t * 4 + (c >> 6)] = 0;
-        unsat[(size_t)t * 4 + (c >> 6)] = 0;
+    if (c == 0) {
+        done[t] = pad;
+        conv[t] = 0;
+        unsat[t] = 0;
     }
 }
 
-// Latch convergence after the parity test of iteration `it`.  grid T, block 256.
+// Latch convergence after the parity test of iteration `it`.  grid G, block 64.
 //   latch = 1 (early exit): a codeword that satisfies H e == s for the first time is
 //           frozen: done bit set, iters = it, its outputs are no longer overwritten.
 //   latch = 0 (fixed iterations): only record whether the FINAL decision satisfies.
-// remaining[slot] += number of codewords still running.
-__global__ __launch_bounds__(256) void k_finalize(int it, int latch, u64 *__restrict__ done, u64 *__restrict__ conv,
-                                                  u64 *__restrict__ unsat, int *__restrict__ iters,
-                                                  int *__restrict__ remaining)
+// *remaining += number of codewords still running.
+__global__ __launch_bounds__(64) void k_finalize(int it, int latch, u64 *__restrict__ done, u64 *__restrict__ conv,
+                                                 u64 *__restrict__ unsat, int *__restrict__ iters,
+                                                 int *__restrict__ remaining)
 {
-    const int t = blockIdx.x, c = threadIdx.x, w = c >> 6, l = c & 63;
-    const u64 uw = unsat[(size_t)t * 4 + w];
-    const u64 dw = done[(size_t)t * 4 + w];
-    __syncthreads();
+    const int t = blockIdx.x, c = threadIdx.x;
+    const u64 uw = unsat[t];
+    const u64 dw = done[t];
     const u64 newly = ~dw & ~uw;
     if (latch) {
-        if ((newly >> l) & 1) iters[(long)t * TW + c] = it;
-        if (l == 0) {
-            done[(size_t)t * 4 + w] = dw | newly;
-            conv[(size_t)t * 4 + w] |= newly;
-            unsat[(size_t)t * 4 + w] = 0;
+        if ((newly >> c) & 1) iters[(long)t * TW + c] = it;
+        if (c == 0) {
+            done[t] = dw | newly;
+            conv[t] |= newly;
+            unsat[t] = 0;
             const int rem = __popcll(~(dw | newly));
             if (rem) atomicAdd(remaining, rem);
         }
-    } else if (l == 0) {
-        conv[(size_t)t * 4 + w] = ~uw & ~dw;  // dw = padding here
-        unsat[(size_t)t * 4 + w] = 0;
+    } else if (c == 0) {
+        conv[t] = newly;  // dw = padding here
+        unsat[t] = 0;
     }
 }
 
 // ---------------------------------------------------------------------------
-// K1  initial bit-to-check messages: v2c[tile][e][:] = LLR prior of the edge's column.
-// grid (ceil(E/4), G), block 256 = 4 waves, wave = one edge row (1 KiB store).
+// K1  initial bit-to-check messages: msg[tile][e][:] = LLR prior of the edge's column.
+// grid (ceil(E/4), G), block 256 = 4 waves, wave = one 256 B edge row.
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_init_v2c(const int *__restrict__ col_idx, const float *__restrict__ prior,
-                                                  float4 *__restrict__ v2c, long E)
+__global__ __launch_bounds__(256) void k_init_msg(const int *__restrict__ col_idx, const float *__restrict__ prior,
+                                                  float *__restrict__ msg, long E)
 {
     const int lane = threadIdx.x & 63;
     const long e = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (e >= E) return;
-    const float p = prior[col_idx[e]];
-    v2c[((size_t)blockIdx.y * E + e) * 64 + lane] = make_float4(p, p, p, p);
+    msg[((size_t)blockIdx.y * E + e) * TW + lane] = prior[col_idx[e]];
 }
 
 // ---------------------------------------------------------------------------
-// K3  min-sum check-node update.
+// K3  min-sum check-node update, in place.
 //   c2v_k = alpha * (-1)^(s + #{k' != k : v2c_k' <= 0}) * min_{k' != k} |v2c_k'|
 // The reference package obtains the exclusive minimum by a forward and a backward
 // running min; min is exact, so (min1, min2, first argmin) gives the identical
 // value with ONE pass over the inputs.  Signs of all inputs are kept in a 64-bit
-// mask per codeword (rows of degree <= 64); WIDE rows re-read the input instead.
-// wave = (row, tile): lane handles 4 codewords (16 B loads / stores).
-// grid (ceil(m/4), G), block 256 = 4 rows.
+// mask per codeword (rows of degree <= 64); WIDE rows re-read the input instead
+// (reading edge k before overwriting edge k keeps that legal in place).
+// wave = (row, tile), lane = codeword.  grid (ceil(m/4), G), block 256 = 4 rows.
 // ---------------------------------------------------------------------------
-#define MS_ACC(x, K, mn1, mn2, ix, par, ng)                      \
-    {                                                            \
-        const float a_ = fabsf(x);                               \
-        const unsigned n_ = (x) <= 0.0f;                         \
-        par ^= n_;                                               \
-        if (!WIDE) ng |= (u64)n_ << (K);                         \
-        const bool lt_ = a_ < mn1;                               \
-        mn2 = lt_ ? mn1 : ((a_ < mn2) ? a_ : mn2);               \
-        ix = lt_ ? (K) : ix;                                     \
-        mn1 = lt_ ? a_ : mn1;                                    \
-    }
-
 template <bool WIDE>
-__global__ __launch_bounds__(256) void k_check_minsum(const int *__restrict__ row_ptr, const float4 *__restrict__ v2c,
-                                                      float4 *__restrict__ c2v, const u64 *__restrict__ synd, int m,
-                                                      long E, float alpha)
+__global__ __launch_bounds__(256) void k_check_minsum(const int *__restrict__ row_ptr, float *msg,
+                                                      const u64 *__restrict__ synd, const u64 *__restrict__ done,
+                                                      int skip_done, int m, long E, float alpha)
 {
     const int lane = threadIdx.x & 63;
     int r = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (r >= m) return;
     r = rfl(r);
     const int tl = blockIdx.y;
+    if (skip_done && done[tl] == ~0ull) return;
     const int e0 = rfl(row_ptr[r]);
     const int deg = rfl(row_ptr[r + 1]) - e0;
-    const size_t base = ((size_t)tl * E + e0) * 64 + lane;
-    const float4 *__restrict__ in = v2c + base;
-    float4 *__restrict__ out = c2v + base;
-    // syndrome bits of codewords 4*lane .. 4*lane+3 (natural plane layout)
-    const u64 sw = synd[((size_t)tl * m + r) * 4 + (lane >> 4)];
-    const unsigned sb = (unsigned)(sw >> ((lane & 15) * 4)) & 0xFu;
-
-    float m1x = FLT_MAX, m1y = FLT_MAX, m1z = FLT_MAX, m1w = FLT_MAX;
-    float m2x = FLT_MAX, m2y = FLT_MAX, m2z = FLT_MAX, m2w = FLT_MAX;
-    int ix = 0, iy = 0, iz = 0, iw = 0;
-    unsigned px = sb & 1, py = (sb >> 1) & 1, pz = (sb >> 2) & 1, pw = (sb >> 3) & 1;
-    u64 nx = 0, ny = 0, nz = 0, nw = 0;
-
-#pragma unroll 4
+    float *p = msg + ((size_t)tl * E + e0) * TW + lane;
+    unsigned par = (unsigned)(synd[(size_t)tl * m + r] >> lane) & 1u;
+    float m1 = FLT_MAX, m2 = FLT_MAX;
+    int ix = 0;
+    u64 neg = 0;
+#pragma unroll 8
     for (int k = 0; k < deg; k++) {
-        const float4 x = in[(size_t)k * 64];
-        MS_ACC(x.x, k, m1x, m2x, ix, px, nx)
-        MS_ACC(x.y, k, m1y, m2y, iy, py, ny)
-        MS_ACC(x.z, k, m1z, m2z, iz, pz, nz)
-        MS_ACC(x.w, k, m1w, m2w, iw, pw, nw)
+        const float x = p[(size_t)k * TW];
+        const float a = fabsf(x);
+        const unsigned n_ = x <= 0.0f;
+        par ^= n_;
+        if (!WIDE) neg |= (u64)n_ << k;
+        const bool lt = a < m1;
+        m2 = lt ? m1 : ((a < m2) ? a : m2);
+        ix = lt ? k : ix;
+        m1 = lt ? a : m1;
     }
     const float nalpha = -alpha;
-#pragma unroll 4
+#pragma unroll 8
     for (int k = 0; k < deg; k++) {
-        unsigned bx, by, bz, bw;
-        if (WIDE) {
-            const float4 x = in[(size_t)k * 64];
-            bx = x.x <= 0.0f; by = x.y <= 0.0f; bz = x.z <= 0.0f; bw = x.w <= 0.0f;
-        } else {
-            bx = (unsigned)(nx >> k) & 1; by = (unsigned)(ny >> k) & 1;
-            bz = (unsigned)(nz >> k) & 1; bw = (unsigned)(nw >> k) & 1;
-        }
-        float4 o;
-        o.x = ((k == ix) ? m2x : m1x) * ((px ^ bx) ? nalpha : alpha);
-        o.y = ((k == iy) ? m2y : m1y) * ((py ^ by) ? nalpha : alpha);
-        o.z = ((k == iz) ? m2z : m1z) * ((pz ^ bz) ? nalpha : alpha);
-        o.w = ((k == iw) ? m2w : m1w) * ((pw ^ bw) ? nalpha : alpha);
-        out[(size_t)k * 64] = o;
+        const unsigned b = WIDE ? (unsigned)(p[(size_t)k * TW] <= 0.0f) : ((unsigned)(neg >> k) & 1u);
+        p[(size_t)k * TW] = ((k == ix) ? m2 : m1) * ((par ^ b) ? nalpha : alpha);
     }
 }
 
 // ---------------------------------------------------------------------------
-// K2  tanh-rule (sum-product) check-node update, LLR domain, fp32, COMPLEMENT form.
+// K2  tanh-rule (sum-product) check-node update, LLR domain, fp32, COMPLEMENT form, in place.
 //   c2v_k = (-1)^(s + #{k' != k : x_k' < 0}) * 2 atanh( prod_{k' != k} tanh(|x_k'|/2) )
 // computed without the 1-x cancellation that saturates the textbook form at |L|~17
 // in fp32:   u_k = 1 - tanh(|x_k|/2) = 2 / (exp|x_k| + 1)
@@ -322,24 +291,29 @@ __global__ __launch_bounds__(256) void k_check_minsum(const int *__restrict__ ro
 // p = 0 priors feed in).  Same exclusive forward/backward sweep as the reference
 // package; the CPU oracle's method 3 is this sequence op for op.
 // Row values live in registers (compile-time unrolled to MAXDEG <= 64, predicated on
-// the wave-uniform degree), signs in a 64-bit mask.  wave = (row, quarter tile).
-// grid (rows in bucket, G), block 256 = the 4 quarters of one (row, tile).
+// the wave-uniform degree), signs in a 64-bit mask.
 // ---------------------------------------------------------------------------
-template <int MAXDEG>
-__global__ __launch_bounds__(256) void k_check_tanh(const int *__restrict__ list, const int *__restrict__ row_ptr,
-                                                    const float *__restrict__ v2c, float *__restrict__ c2v,
-                                                    const u64 *__restrict__ synd, int m, long E)
+// Device math for the tanh rule: the hardware transcendental units (v_exp_f32,
+// v_rcp_f32, v_log_f32; ~1 ulp each) instead of the ~100-instruction-per-edge
+// correctly rounded expf / logf / IEEE division, which made this kernel ALU-bound once
+// the messages were cache resident.  The complement form does not amplify these
+// errors (|dL| stays ~1e-6 relative, tests/helpers.compare states the tolerance).
+__device__ __forceinline__ float tanh_compl(float a)  // 1 - tanh(a/2) = 2 / (e^a + 1), a >= 0
 {
-    const int q = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int r = rfl(list[blockIdx.x]);
-    const int tl = blockIdx.y;
-    const int e0 = rfl(row_ptr[r]);
-    const int deg = rfl(row_ptr[r + 1]) - e0;
-    const size_t base = ((size_t)tl * E + e0) * TW + q * 64 + lane;
+    return 2.0f * __builtin_amdgcn_rcpf(__expf(a) + 1.0f);
+}
+__device__ __forceinline__ float llr_from_compl(float U)  // 2 atanh(1 - U) = log(2/U - 1)
+{
+    return __logf(2.0f * __builtin_amdgcn_rcpf(U) - 1.0f);
+}
+
+template <int MAXDEG>
+__device__ __forceinline__ void check_tanh_row(float *p, int deg, unsigned sbit)
+{
     float uu[MAXDEG], pre[MAXDEG];
 #pragma unroll
     for (int k = 0; k < MAXDEG; k++)
-        if (k < deg) uu[k] = v2c[base + (size_t)k * TW];
+        if (k < deg) uu[k] = p[(size_t)k * TW];
     u64 neg = 0;
     float U = 0.0f;
 #pragma unroll
@@ -347,204 +321,193 @@ __global__ __launch_bounds__(256) void k_check_tanh(const int *__restrict__ list
         if (k < deg) {
             const float x = uu[k];
             neg |= (u64)(x < 0.0f) << k;
-            const float u = 2.0f / (expf(fabsf(x)) + 1.0f);
+            const float u = tanh_compl(fabsf(x));
             uu[k] = u;
             pre[k] = U;
             U = U + u * (1.0f - U);
         }
-    const unsigned tot = ((unsigned)__popcll(neg) ^ (unsigned)(synd[((size_t)tl * m + r) * 4 + q] >> lane)) & 1u;
+    const unsigned tot = ((unsigned)__popcll(neg) ^ sbit) & 1u;
     U = 0.0f;
 #pragma unroll
     for (int k = MAXDEG - 1; k >= 0; k--)
         if (k < deg) {
             const float Ut = pre[k] + U * (1.0f - pre[k]);
-            const float Lm = logf(2.0f / Ut - 1.0f);
-            c2v[base + (size_t)k * TW] = ((tot ^ (unsigned)(neg >> k)) & 1u) ? -Lm : Lm;
+            const float Lm = llr_from_compl(Ut);
+            p[(size_t)k * TW] = ((tot ^ (unsigned)(neg >> k)) & 1u) ? -Lm : Lm;
             U = U + uu[k] * (1.0f - U);
         }
 }
 
-// Any-degree fallback: the forward sweep parks Upre in c2v itself (as the reference
-// package parks its prefix products), the backward sweep re-reads v2c and recomputes u.
-// grid (rows in list, G), block 256.
-__global__ __launch_bounds__(256) void k_check_tanh_generic(const int *__restrict__ list,
-                                                            const int *__restrict__ row_ptr,
-                                                            const float *__restrict__ v2c, float *c2v,
-                                                            const u64 *__restrict__ synd, int m, long E)
+// Any-degree fallback: the forward sweep parks Upre in a scratch array (the reference
+// package parks its prefix products in the message slot), the backward sweep re-reads
+// the inputs and recomputes u before overwriting them.
+__device__ __forceinline__ void check_tanh_row_generic(float *p, float *sc, int deg, unsigned sbit)
 {
-    const int q = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int r = rfl(list[blockIdx.x]);
-    const int tl = blockIdx.y;
-    const int e0 = rfl(row_ptr[r]);
-    const int deg = rfl(row_ptr[r + 1]) - e0;
-    const size_t base = ((size_t)tl * E + e0) * TW + q * 64 + lane;
     float U = 0.0f;
-    unsigned par = (unsigned)(synd[((size_t)tl * m + r) * 4 + q] >> lane) & 1u;
+    unsigned par = sbit;
     for (int k = 0; k < deg; k++) {
-        const float x = v2c[base + (size_t)k * TW];
-        c2v[base + (size_t)k * TW] = U;
+        const float x = p[(size_t)k * TW];
+        sc[(size_t)k * TW] = U;
         par ^= (unsigned)(x < 0.0f);
-        const float u = 2.0f / (expf(fabsf(x)) + 1.0f);
+        const float u = tanh_compl(fabsf(x));
         U = U + u * (1.0f - U);
     }
     U = 0.0f;
     for (int k = deg - 1; k >= 0; k--) {
-        const float x = v2c[base + (size_t)k * TW];
-        const float p = c2v[base + (size_t)k * TW];
-        const float Ut = p + U * (1.0f - p);
-        const float Lm = logf(2.0f / Ut - 1.0f);
-        c2v[base + (size_t)k * TW] = ((par ^ (unsigned)(x < 0.0f)) & 1u) ? -Lm : Lm;
-        const float u = 2.0f / (expf(fabsf(x)) + 1.0f);
+        const float x = p[(size_t)k * TW];
+        const float pk = sc[(size_t)k * TW];
+        const float Ut = pk + U * (1.0f - pk);
+        const float Lm = llr_from_compl(Ut);
+        p[(size_t)k * TW] = ((par ^ (unsigned)(x < 0.0f)) & 1u) ? -Lm : Lm;
+        const float u = tanh_compl(fabsf(x));
         U = U + u * (1.0f - U);
     }
 }
 
+// One fused launch over all row-degree buckets.  wave = (row, tile).
+// CAP = largest unroll bound compiled in (register budget follows the widest bucket,
+// so graphs with narrow rows get the high-occupancy instantiation).
+// grid (bk.blk[nb], G), block 256 = 4 rows of one bucket.
+template <int CAP>
+__global__ __launch_bounds__(256) void k_check_tanh(Buckets bk, const int *__restrict__ list,
+                                                    const int *__restrict__ row_ptr, float *msg, float *scratch,
+                                                    const u64 *__restrict__ synd, const u64 *__restrict__ done,
+                                                    int skip_done, int m, long E)
+{
+    const int lane = threadIdx.x & 63;
+    const int tl = blockIdx.y;
+    if (skip_done && done[tl] == ~0ull) return;
+    int b = 0;
+    while (b + 1 < bk.nb && (int)blockIdx.x >= bk.blk[b + 1]) b++;
+    const int slot = ((int)blockIdx.x - bk.blk[b]) * 4 + (threadIdx.x >> 6);
+    if (slot >= bk.cnt[b]) return;
+    const int r = rfl(list[bk.off[b] + slot]);
+    const int e0 = rfl(row_ptr[r]);
+    const int deg = rfl(row_ptr[r + 1]) - e0;
+    const size_t base = ((size_t)tl * E + e0) * TW + lane;
+    float *p = msg + base;
+    const unsigned sbit = (unsigned)(synd[(size_t)tl * m + r] >> lane) & 1u;
+    switch (bk.maxd[b]) {
+        case 2: check_tanh_row<2>(p, deg, sbit); break;
+        case 4: check_tanh_row<4>(p, deg, sbit); break;
+        case 8: check_tanh_row<8>(p, deg, sbit); break;
+        case 16: check_tanh_row<16>(p, deg, sbit); break;
+        case 32:
+            if constexpr (CAP >= 32) check_tanh_row<32>(p, deg, sbit);
+            break;
+        case 64:
+            if constexpr (CAP >= 64) check_tanh_row<64>(p, deg, sbit);
+            break;
+        default: check_tanh_row_generic(p, scratch + base, deg, sbit);
+    }
+}
+
 // ---------------------------------------------------------------------------
-// K4  variable-node update + posterior + hard decision.
+// K4  variable-node update + posterior + hard decision, in place.
 //   prefix : v2c_k = prior + sum_{k'<k} c2v_k'      (ascending row)
 //   total  : L = prior + sum_k c2v_k ; e = [L <= 0]
 //   suffix : v2c_k += sum_{k'>k} c2v_k'             (accumulated from the last edge)
-// Column values live in registers (unrolled to MAXD, predicated on the uniform
-// degree); columns are bucketed by degree on the host.  wave = (column, half
-// tile): lane handles 2 codewords (8 B), the two halves of a 1 KiB edge row are
-// fetched by adjacent waves of one block.
-// grid (ceil(count/2), G), block 256 = 2 columns x 2 halves.
-// write_out: also emit hard-decision planes (merged under the done mask) and, if
-// `post` is non-null, the posterior of every not-yet-frozen codeword.
+// Column values live in registers (unrolled to MAXD, predicated on the uniform degree).
+// Returns the posterior L.
 // ---------------------------------------------------------------------------
 template <int MAXD>
-__global__ __launch_bounds__(256) void k_var(const int *__restrict__ list, int count, const int *__restrict__ col_ptr,
-                                             const int *__restrict__ csc_edge, const float *__restrict__ prior,
-                                             const float *__restrict__ c2v, float *__restrict__ v2c,
-                                             float *__restrict__ post, u64 *__restrict__ hard,
-                                             const u64 *__restrict__ done, int n, long E, int write_out)
+__device__ __forceinline__ float var_col(float *mt, const int *__restrict__ ce, int d, float pr)
 {
-    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int slot = blockIdx.x * 2 + (w >> 1);
-    if (slot >= count) return;
-    const int half = w & 1;
-    const int tl = blockIdx.y;
-    const int v = rfl(list[slot]);
-    const int cb = rfl(col_ptr[v]);
-    const int d = rfl(col_ptr[v + 1]) - cb;
-    const size_t lane_off = (size_t)half * 128 + lane * 2;
-    const size_t tile_off = (size_t)tl * E;
-
-    float2 mm[MAXD], pp[MAXD];
+    float mm[MAXD], pp[MAXD];
 #pragma unroll
     for (int k = 0; k < MAXD; k++)
-        if (k < d) {
-            const int e = rfl(csc_edge[cb + k]);
-            mm[k] = *(const float2 *)(c2v + (tile_off + e) * TW + lane_off);
-        }
-    const float pr = prior[v];
-    float2 temp = make_float2(pr, pr);
+        if (k < d) mm[k] = mt[(size_t)rfl(ce[k]) * TW];
+    float temp = pr;
 #pragma unroll
     for (int k = 0; k < MAXD; k++)
         if (k < d) {
             pp[k] = temp;
-            temp.x += mm[k].x;
-            temp.y += mm[k].y;
+            temp += mm[k];
         }
-    float2 suf = make_float2(0.0f, 0.0f);
+    float suf = 0.0f;
 #pragma unroll
     for (int k = MAXD - 1; k >= 0; k--)
         if (k < d) {
-            const int e = rfl(csc_edge[cb + k]);
-            float2 o;
-            o.x = pp[k].x + suf.x;
-            o.y = pp[k].y + suf.y;
-            *(float2 *)(v2c + (tile_off + e) * TW + lane_off) = o;
-            suf.x += mm[k].x;
-            suf.y += mm[k].y;
+            mt[(size_t)rfl(ce[k]) * TW] = pp[k] + suf;
+            suf += mm[k];
         }
-    if (write_out) {
-        // codewords c = 128*half + 2*lane + i  ->  plane word 2*half + (lane>>5), bit 2*(lane&31)+i
-        const u64 b0 = __ballot(temp.x <= 0.0f), b1 = __ballot(temp.y <= 0.0f);
-        const u64 w0 = spread32(b0) | (spread32(b1) << 1);
-        const u64 w1 = spread32(b0 >> 32) | (spread32(b1 >> 32) << 1);
-        const size_t hi = ((size_t)tl * n + v) * 4 + 2 * half;
-        const u64 d0 = done[(size_t)tl * 4 + 2 * half], d1 = done[(size_t)tl * 4 + 2 * half + 1];
-        if (lane == 0) {
-            hard[hi] = (hard[hi] & d0) | (w0 & ~d0);
-            hard[hi + 1] = (hard[hi + 1] & d1) | (w1 & ~d1);
-        }
-        if (post) {
-            const u64 dw = (lane >> 5) ? d1 : d0;
-            const unsigned db = (unsigned)(dw >> (2 * (lane & 31))) & 3u;
-            float *p = post + ((size_t)tl * n + v) * TW + lane_off;
-            if (db == 0)
-                *(float2 *)p = temp;
-            else {
-                if (!(db & 1)) p[0] = temp.x;
-                if (!(db & 2)) p[1] = temp.y;
-            }
-        }
-    }
+    return temp;
 }
 
-// Any-degree fallback (columns wider than the largest bucket): prefix parked in
-// v2c, second sweep re-reads c2v.  Same launch geometry as k_var.
-__global__ __launch_bounds__(256) void k_var_generic(const int *__restrict__ list, int count,
-                                                     const int *__restrict__ col_ptr, const int *__restrict__ csc_edge,
-                                                     const float *__restrict__ prior, const float *__restrict__ c2v,
-                                                     float *v2c, float *__restrict__ post, u64 *__restrict__ hard,
-                                                     const u64 *__restrict__ done, int n, long E, int write_out)
+// Any-degree fallback: prefix parked in the scratch array, second sweep re-reads c2v
+// just before overwriting it.
+__device__ __forceinline__ float var_col_generic(float *mt, float *st, const int *__restrict__ ce, int d, float pr)
 {
-    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int slot = blockIdx.x * 2 + (w >> 1);
-    if (slot >= count) return;
-    const int half = w & 1;
+    float temp = pr;
+    for (int k = 0; k < d; k++) {
+        const size_t o = (size_t)ce[k] * TW;
+        st[o] = temp;
+        temp += mt[o];
+    }
+    float suf = 0.0f;
+    for (int k = d - 1; k >= 0; k--) {
+        const size_t o = (size_t)ce[k] * TW;
+        const float mk = mt[o];
+        mt[o] = st[o] + suf;
+        suf += mk;
+    }
+    return temp;
+}
+
+// One fused launch over all column-degree buckets.  wave = (column, tile), lane = codeword.
+// grid (bk.blk[nb], G), block 256 = 4 columns of one bucket.
+// write_out: also emit hard-decision planes (merged under the done mask) and, if
+// `post` is non-null, the posterior of every not-yet-frozen codeword.
+// CAP = largest unroll bound compiled in (see k_check_tanh).
+template <int CAP>
+__global__ __launch_bounds__(256) void k_var(Buckets bk, const int *__restrict__ list,
+                                             const int *__restrict__ col_ptr, const int *__restrict__ csc_edge,
+                                             const float *__restrict__ prior, float *msg, float *scratch,
+                                             float *__restrict__ post, u64 *__restrict__ hard,
+                                             const u64 *__restrict__ done, int skip_done, int n, long E,
+                                             int write_out)
+{
+    const int lane = threadIdx.x & 63;
     const int tl = blockIdx.y;
-    const int v = rfl(list[slot]);
+    const u64 dn = done[tl];
+    if (skip_done && dn == ~0ull) return;
+    int b = 0;
+    while (b + 1 < bk.nb && (int)blockIdx.x >= bk.blk[b + 1]) b++;
+    const int slot = ((int)blockIdx.x - bk.blk[b]) * 4 + (threadIdx.x >> 6);
+    if (slot >= bk.cnt[b]) return;
+    const int v = rfl(list[bk.off[b] + slot]);
     const int cb = rfl(col_ptr[v]);
     const int d = rfl(col_ptr[v + 1]) - cb;
-    const size_t lane_off = (size_t)half * 128 + lane * 2;
-    const size_t tile_off = (size_t)tl * E;
+    float *mt = msg + (size_t)tl * E * TW + lane;
+    const int *ce = csc_edge + cb;
     const float pr = prior[v];
-    float2 temp = make_float2(pr, pr);
-    for (int k = 0; k < d; k++) {
-        const int e = csc_edge[cb + k];
-        const float2 mk = *(const float2 *)(c2v + (tile_off + e) * TW + lane_off);
-        *(float2 *)(v2c + (tile_off + e) * TW + lane_off) = temp;
-        temp.x += mk.x;
-        temp.y += mk.y;
-    }
-    float2 suf = make_float2(0.0f, 0.0f);
-    for (int k = d - 1; k >= 0; k--) {
-        const int e = csc_edge[cb + k];
-        const float2 mk = *(const float2 *)(c2v + (tile_off + e) * TW + lane_off);
-        float2 o = *(float2 *)(v2c + (tile_off + e) * TW + lane_off);
-        o.x += suf.x;
-        o.y += suf.y;
-        *(float2 *)(v2c + (tile_off + e) * TW + lane_off) = o;
-        suf.x += mk.x;
-        suf.y += mk.y;
+    float L = pr;
+    switch (bk.maxd[b]) {
+        case 1: L = var_col<1>(mt, ce, d, pr); break;
+        case 2: L = var_col<2>(mt, ce, d, pr); break;
+        case 4: L = var_col<4>(mt, ce, d, pr); break;
+        case 8: L = var_col<8>(mt, ce, d, pr); break;
+        case 16: L = var_col<16>(mt, ce, d, pr); break;
+        case 32:
+            if constexpr (CAP >= 32) L = var_col<32>(mt, ce, d, pr);
+            break;
+        case 64:
+            if constexpr (CAP >= 64) L = var_col<64>(mt, ce, d, pr);
+            break;
+        default: L = var_col_generic(mt, scratch + (size_t)tl * E * TW + lane, ce, d, pr);
     }
     if (write_out) {
-        const u64 b0 = __ballot(temp.x <= 0.0f), b1 = __ballot(temp.y <= 0.0f);
-        const u64 w0 = spread32(b0) | (spread32(b1) << 1);
-        const u64 w1 = spread32(b0 >> 32) | (spread32(b1 >> 32) << 1);
-        const size_t hi = ((size_t)tl * n + v) * 4 + 2 * half;
-        const u64 d0 = done[(size_t)tl * 4 + 2 * half], d1 = done[(size_t)tl * 4 + 2 * half + 1];
-        if (lane == 0) {
-            hard[hi] = (hard[hi] & d0) | (w0 & ~d0);
-            hard[hi + 1] = (hard[hi + 1] & d1) | (w1 & ~d1);
-        }
-        if (post) {
-            const u64 dw = (lane >> 5) ? d1 : d0;
-            const unsigned db = (unsigned)(dw >> (2 * (lane & 31))) & 3u;
-            float *p = post + ((size_t)tl * n + v) * TW + lane_off;
-            if (!(db & 1)) p[0] = temp.x;
-            if (!(db & 2)) p[1] = temp.y;
-        }
+        const u64 hb = __ballot(L <= 0.0f);
+        const size_t hi = (size_t)tl * n + v;
+        if (lane == 0) hard[hi] = (hard[hi] & dn) | (hb & ~dn);
+        if (post && !((dn >> lane) & 1)) post[hi * TW + lane] = L;
     }
 }
 
-struct Bucket {
-    int maxd;   // unroll bound (0 = generic kernel)
-    int off;    // offset into the list
-    int count;  // nodes in the bucket
+struct HostBuckets {
+    Buckets bk;
+    std::vector<int> list;
+    bool has_generic = false;
 };
 
 }  // namespace
@@ -555,17 +518,18 @@ struct Bucket {
 struct scaldpc_bp {
     int m = 0, n = 0;
     long E = 0;
-    int max_row_deg = 0;
+    int max_row_deg = 0, max_col_deg = 0;
     // device graph
     int *d_row_ptr = nullptr, *d_col_idx = nullptr, *d_col_ptr = nullptr, *d_csc_edge = nullptr;
     int *d_var_list = nullptr, *d_row_list = nullptr;
-    std::vector<Bucket> var_buckets, row_buckets;
+    Buckets var_bk{}, row_bk{};
+    bool need_scratch = false;
     // priors
     float *d_prior = nullptr;
     bool have_prior = false;
     // workspace (state arrays sized for cap_tiles, messages for cap_group tiles)
     int cap_tiles = 0, cap_group = 0, tile_group = 0;
-    float *d_v2c = nullptr, *d_c2v = nullptr, *d_post = nullptr;
+    float *d_msg = nullptr, *d_scratch = nullptr, *d_post = nullptr;
     u64 *d_synd = nullptr, *d_recv = nullptr, *d_hard = nullptr, *d_done = nullptr, *d_conv = nullptr,
         *d_unsat = nullptr;
     int *d_iters = nullptr, *d_remaining = nullptr;
@@ -578,17 +542,15 @@ struct scaldpc_bp {
     size_t cap_in = 0, cap_out_bits = 0, cap_out_llr = 0, cap_out_b = 0;
     int *h_remaining = nullptr;  // pinned
     hipStream_t own_stream = nullptr;
-    // last decode geometry (for scaldpc_bp_time_kernels)
-    int last_group = 0;
+    int last_group = 0;  // tiles of the last decoded group (for scaldpc_bp_time_kernels)
     std::mutex mu;
 };
 
 namespace {
 
-int build_buckets(const std::vector<int> &deg, const int *bounds, int nb, bool keep_isolated,
-                  std::vector<int> &list, std::vector<Bucket> &out)
+// bucket b holds nodes with bounds[b-1] < deg <= bounds[b]; beyond the last bound -> generic (maxd 0)
+void build_buckets(const std::vector<int> &deg, const int *bounds, int nb, bool keep_isolated, HostBuckets &out)
 {
-    // bucket b holds nodes with bounds[b-1] < deg <= bounds[b]; beyond the last bound -> generic (maxd 0)
     std::vector<std::vector<int>> tmp(nb + 1);
     for (int i = 0; i < (int)deg.size(); i++) {
         // an isolated check has nothing to send; an isolated VARIABLE still owes its
@@ -598,18 +560,19 @@ int build_buckets(const std::vector<int> &deg, const int *bounds, int nb, bool k
         while (b < nb && deg[i] > bounds[b]) b++;
         tmp[b].push_back(i);
     }
-    list.clear();
-    out.clear();
+    out.list.clear();
+    Buckets &bk = out.bk;
+    memset(&bk, 0, sizeof bk);
     for (int b = 0; b <= nb; b++) {
         if (tmp[b].empty()) continue;
-        Bucket bk;
-        bk.maxd = b < nb ? bounds[b] : 0;
-        bk.off = (int)list.size();
-        bk.count = (int)tmp[b].size();
-        list.insert(list.end(), tmp[b].begin(), tmp[b].end());
-        out.push_back(bk);
+        const int i = bk.nb++;
+        bk.maxd[i] = b < nb ? bounds[b] : 0;
+        if (b == nb) out.has_generic = true;
+        bk.off[i] = (int)out.list.size();
+        bk.cnt[i] = (int)tmp[b].size();
+        bk.blk[i + 1] = bk.blk[i] + (bk.cnt[i] + 3) / 4;
+        out.list.insert(out.list.end(), tmp[b].begin(), tmp[b].end());
     }
-    return 0;
 }
 
 template <typename T>
@@ -623,6 +586,17 @@ int grow(T **p, size_t *cap, size_t need)
     return 0;
 }
 
+// tiles per group: the in-place message array of a group should stay resident in the
+// 256 MiB Infinity Cache (measured knee between 209 and 261 MB, profiles/microbench)
+int auto_group(const scaldpc_bp *h, int T)
+{
+    double budget = 215e6;  // 4 tiles of the HQC-128 bench graph = 208.9 MB: fastest measured; 261 MB falls off
+    if (const char *e = getenv("SCALDPC_GROUP_MB")) budget = atof(e) * 1e6;
+    const double per_tile = (double)h->E * TW * sizeof(float);
+    const int g = per_tile > 0 ? (int)(budget / per_tile) : T;
+    return std::max(1, std::min(g, T));
+}
+
 int ensure_workspace(scaldpc_bp *h, int T, int G, bool want_post, int max_iter)
 {
     if (T > h->cap_tiles) {
@@ -630,12 +604,12 @@ int ensure_workspace(scaldpc_bp *h, int T, int G, bool want_post, int max_iter)
         dev_free(h->d_conv); dev_free(h->d_unsat); dev_free(h->d_iters); dev_free(h->d_post);
         h->cap_tiles = 0;
         h->post_alloc = false;
-        SC_TRY(dev_alloc(&h->d_synd, (size_t)T * h->m * 4));
-        SC_TRY(dev_alloc(&h->d_recv, (size_t)T * h->n * 4));
-        SC_TRY(dev_alloc(&h->d_hard, (size_t)T * h->n * 4));
-        SC_TRY(dev_alloc(&h->d_done, (size_t)T * 4));
-        SC_TRY(dev_alloc(&h->d_conv, (size_t)T * 4));
-        SC_TRY(dev_alloc(&h->d_unsat, (size_t)T * 4));
+        SC_TRY(dev_alloc(&h->d_synd, (size_t)T * h->m));
+        SC_TRY(dev_alloc(&h->d_recv, (size_t)T * h->n));
+        SC_TRY(dev_alloc(&h->d_hard, (size_t)T * h->n));
+        SC_TRY(dev_alloc(&h->d_done, (size_t)T));
+        SC_TRY(dev_alloc(&h->d_conv, (size_t)T));
+        SC_TRY(dev_alloc(&h->d_unsat, (size_t)T));
         SC_TRY(dev_alloc(&h->d_iters, (size_t)T * TW));
         h->cap_tiles = T;
     }
@@ -644,10 +618,10 @@ int ensure_workspace(scaldpc_bp *h, int T, int G, bool want_post, int max_iter)
         h->post_alloc = true;
     }
     if (G > h->cap_group) {
-        dev_free(h->d_v2c); dev_free(h->d_c2v);
+        dev_free(h->d_msg); dev_free(h->d_scratch);
         h->cap_group = 0;
-        SC_TRY(dev_alloc(&h->d_v2c, (size_t)G * h->E * TW));
-        SC_TRY(dev_alloc(&h->d_c2v, (size_t)G * h->E * TW));
+        SC_TRY(dev_alloc(&h->d_msg, (size_t)G * h->E * TW));
+        if (h->need_scratch) SC_TRY(dev_alloc(&h->d_scratch, (size_t)G * h->E * TW));
         h->cap_group = G;
     }
     if (max_iter + 2 > h->cap_remaining) {
@@ -664,68 +638,49 @@ int ensure_workspace(scaldpc_bp *h, int T, int G, bool want_post, int max_iter)
 
 #define LAUNCH_CHECK() SC_HIP(hipGetLastError())
 
-int launch_check(scaldpc_bp *h, int method, float alpha, int G, const u64 *synd_g, hipStream_t s)
+int launch_check(scaldpc_bp *h, int method, float alpha, int G, const u64 *synd_g, const u64 *done_g, int skip_done,
+                 hipStream_t s)
 {
+    if (h->E == 0) return 0;
     if (method == SCALDPC_BP_MIN_SUM) {
         dim3 grid((h->m + 3) / 4, G);
-        if (h->max_row_deg <= 64)
-            hipLaunchKernelGGL(k_check_minsum<false>, grid, dim3(256), 0, s, h->d_row_ptr, (const float4 *)h->d_v2c,
-                               (float4 *)h->d_c2v, synd_g, h->m, h->E, alpha);
+        if (h->max_row_deg <= ROW_CAP)
+            hipLaunchKernelGGL(k_check_minsum<false>, grid, dim3(256), 0, s, h->d_row_ptr, h->d_msg, synd_g, done_g,
+                               skip_done, h->m, h->E, alpha);
         else
-            hipLaunchKernelGGL(k_check_minsum<true>, grid, dim3(256), 0, s, h->d_row_ptr, (const float4 *)h->d_v2c,
-                               (float4 *)h->d_c2v, synd_g, h->m, h->E, alpha);
-        LAUNCH_CHECK();
-        return 0;
+            hipLaunchKernelGGL(k_check_minsum<true>, grid, dim3(256), 0, s, h->d_row_ptr, h->d_msg, synd_g, done_g,
+                               skip_done, h->m, h->E, alpha);
+    } else {
+        dim3 grid(h->row_bk.blk[h->row_bk.nb], G);
+        if (h->max_row_deg <= 16)
+            hipLaunchKernelGGL(k_check_tanh<16>, grid, dim3(256), 0, s, h->row_bk, h->d_row_list, h->d_row_ptr, h->d_msg,
+                               h->d_scratch, synd_g, done_g, skip_done, h->m, h->E);
+        else if (h->max_row_deg <= 32)
+            hipLaunchKernelGGL(k_check_tanh<32>, grid, dim3(256), 0, s, h->row_bk, h->d_row_list, h->d_row_ptr, h->d_msg,
+                               h->d_scratch, synd_g, done_g, skip_done, h->m, h->E);
+        else
+            hipLaunchKernelGGL(k_check_tanh<64>, grid, dim3(256), 0, s, h->row_bk, h->d_row_list, h->d_row_ptr, h->d_msg,
+                               h->d_scratch, synd_g, done_g, skip_done, h->m, h->E);
     }
-    for (const Bucket &b : h->row_buckets) {
-        dim3 grid(b.count, G);
-        const int *list = h->d_row_list + b.off;
-#define TANH_CASE(D)                                                                                             \
-    case D:                                                                                                      \
-        hipLaunchKernelGGL(k_check_tanh<D>, grid, dim3(256), 0, s, list, h->d_row_ptr, h->d_v2c, h->d_c2v, synd_g, \
-                           h->m, h->E);                                                                          \
-        break;
-        switch (b.maxd) {
-            TANH_CASE(2)
-            TANH_CASE(4)
-            TANH_CASE(8)
-            TANH_CASE(16)
-            TANH_CASE(32)
-            TANH_CASE(64)
-            default:
-                hipLaunchKernelGGL(k_check_tanh_generic, grid, dim3(256), 0, s, list, h->d_row_ptr, h->d_v2c, h->d_c2v,
-                                   synd_g, h->m, h->E);
-        }
-#undef TANH_CASE
-        LAUNCH_CHECK();
-    }
+    LAUNCH_CHECK();
     return 0;
 }
 
-int launch_var(scaldpc_bp *h, int G, float *post_g, u64 *hard_g, const u64 *done_g, int write_out, hipStream_t s)
+int launch_var(scaldpc_bp *h, int G, float *post_g, u64 *hard_g, const u64 *done_g, int skip_done, int write_out,
+               hipStream_t s)
 {
-    for (const Bucket &b : h->var_buckets) {
-        dim3 grid((b.count + 1) / 2, G);
-        const int *list = h->d_var_list + b.off;
-#define VAR_CASE(D)                                                                                               \
-    case D:                                                                                                       \
-        hipLaunchKernelGGL(k_var<D>, grid, dim3(256), 0, s, list, b.count, h->d_col_ptr, h->d_csc_edge, h->d_prior, \
-                           h->d_c2v, h->d_v2c, post_g, hard_g, done_g, h->n, h->E, write_out);                     \
-        break;
-        switch (b.maxd) {
-            VAR_CASE(1)
-            VAR_CASE(2)
-            VAR_CASE(4)
-            VAR_CASE(8)
-            VAR_CASE(16)
-            VAR_CASE(32)
-            default:
-                hipLaunchKernelGGL(k_var_generic, grid, dim3(256), 0, s, list, b.count, h->d_col_ptr, h->d_csc_edge,
-                                   h->d_prior, h->d_c2v, h->d_v2c, post_g, hard_g, done_g, h->n, h->E, write_out);
-        }
-#undef VAR_CASE
-        LAUNCH_CHECK();
-    }
+    dim3 grid(h->var_bk.blk[h->var_bk.nb], G);
+#define VAR_LAUNCH(CAP)                                                                                             \
+    hipLaunchKernelGGL(k_var<CAP>, grid, dim3(256), 0, s, h->var_bk, h->d_var_list, h->d_col_ptr, h->d_csc_edge,      \
+                       h->d_prior, h->d_msg, h->d_scratch, post_g, hard_g, done_g, skip_done, h->n, h->E, write_out)
+    if (h->max_col_deg <= 16)
+        VAR_LAUNCH(16);
+    else if (h->max_col_deg <= 32)
+        VAR_LAUNCH(32);
+    else
+        VAR_LAUNCH(64);
+#undef VAR_LAUNCH
+    LAUNCH_CHECK();
     return 0;
 }
 
@@ -793,12 +748,16 @@ int scaldpc_bp_create(int32_t m, int32_t n, int64_t nnz, const int32_t *row_ptr,
     h->n = n;
     h->E = nnz;
     h->max_row_deg = m ? *std::max_element(rdeg.begin(), rdeg.end()) : 0;
+    h->max_col_deg = *std::max_element(cdeg.begin(), cdeg.end());
 
-    static const int vb[] = {1, 2, 4, 8, 16, 32};
+    static const int vb[] = {1, 2, 4, 8, 16, 32, 64};
     static const int rb[] = {2, 4, 8, 16, 32, 64};
-    std::vector<int> vlist, rlist;
-    build_buckets(cdeg, vb, 6, true, vlist, h->var_buckets);
-    build_buckets(rdeg, rb, 6, false, rlist, h->row_buckets);
+    HostBuckets hv, hr;
+    build_buckets(cdeg, vb, 7, true, hv);
+    build_buckets(rdeg, rb, 6, false, hr);
+    h->var_bk = hv.bk;
+    h->row_bk = hr.bk;
+    h->need_scratch = hv.has_generic || hr.has_generic;
 
     int rc = 0;
     auto up = [&](int **d, const int *src, size_t cnt) -> int {
@@ -810,8 +769,8 @@ int scaldpc_bp_create(int32_t m, int32_t n, int64_t nnz, const int32_t *row_ptr,
     if (!rc) rc = up(&h->d_col_idx, col_idx, (size_t)nnz);
     if (!rc) rc = up(&h->d_col_ptr, col_ptr.data(), (size_t)n + 1);
     if (!rc) rc = up(&h->d_csc_edge, csc_edge.data(), (size_t)nnz);
-    if (!rc) rc = up(&h->d_var_list, vlist.data(), vlist.size());
-    if (!rc) rc = up(&h->d_row_list, rlist.data(), rlist.size());
+    if (!rc) rc = up(&h->d_var_list, hv.list.data(), hv.list.size());
+    if (!rc) rc = up(&h->d_row_list, hr.list.data(), hr.list.size());
     if (!rc) rc = dev_alloc(&h->d_prior, (size_t)n);
     if (!rc && hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking) != hipSuccess)
         rc = fail(SCALDPC_EHIP, "hipStreamCreate failed");
@@ -869,7 +828,8 @@ int scaldpc_bp_decode_batch(scaldpc_bp *h, const uint8_t *in, int32_t input_kind
     hipStream_t s = stream ? (hipStream_t)stream : h->own_stream;
 
     const int T = (batch + TW - 1) / TW;
-    const int G = (h->tile_group > 0 && h->tile_group < T) ? h->tile_group : T;
+    if (T > 65535) return fail(SCALDPC_EINVAL, "batch %d too large for one call (max %d)", batch, 65535 * TW);
+    const int G = (h->tile_group > 0) ? std::min(h->tile_group, T) : auto_group(h, T);
     const int len = input_kind == SCALDPC_IN_SYNDROME ? h->m : h->n;
     SC_TRY(ensure_workspace(h, T, G, out_llr != nullptr, max_iter));
 
@@ -881,46 +841,48 @@ int scaldpc_bp_decode_batch(scaldpc_bp *h, const uint8_t *in, int32_t input_kind
         din = h->d_in;
     }
     if (input_kind == SCALDPC_IN_SYNDROME) {
-        hipLaunchKernelGGL(k_pack_bits, dim3(h->m, T), dim3(256), 0, s, din, h->m, batch, h->d_synd);
+        hipLaunchKernelGGL(k_pack_bits, dim3((h->m + 63) / 64, T), dim3(256), 0, s, din, h->m, batch, h->d_synd);
         LAUNCH_CHECK();
     } else {
-        hipLaunchKernelGGL(k_pack_bits, dim3(h->n, T), dim3(256), 0, s, din, h->n, batch, h->d_recv);
+        hipLaunchKernelGGL(k_pack_bits, dim3((h->n + 63) / 64, T), dim3(256), 0, s, din, h->n, batch, h->d_recv);
         LAUNCH_CHECK();
         hipLaunchKernelGGL(k_parity<false>, dim3((h->m + 255) / 256, T), dim3(256), 0, s, h->d_row_ptr, h->d_col_idx,
-                           h->d_recv, h->m, h->n, h->d_synd, (u64 *)nullptr);
+                           h->d_recv, h->m, h->n, h->d_synd, (u64 *)nullptr, (const u64 *)nullptr);
         LAUNCH_CHECK();
     }
-    hipLaunchKernelGGL(k_init_state, dim3(T), dim3(256), 0, s, batch, max_iter, h->d_done, h->d_conv, h->d_unsat,
+    hipLaunchKernelGGL(k_init_state, dim3(T), dim3(64), 0, s, batch, max_iter, h->d_done, h->d_conv, h->d_unsat,
                        h->d_iters);
     LAUNCH_CHECK();
-    SC_HIP(hipMemsetAsync(h->d_hard, 0, sizeof(u64) * (size_t)T * h->n * 4, s));
+    SC_HIP(hipMemsetAsync(h->d_hard, 0, sizeof(u64) * (size_t)T * h->n, s));
 
-    // ---- iterate, one tile group at a time -----------------------------------
+    // ---- iterate, one cache-resident tile group at a time ----------------------
     const int poll_every = 4;
+    const int skip = early ? 1 : 0;
     for (int g0 = 0; g0 < T; g0 += G) {
         const int g = std::min(G, T - g0);
-        const u64 *synd_g = h->d_synd + (size_t)g0 * h->m * 4;
-        u64 *hard_g = h->d_hard + (size_t)g0 * h->n * 4;
-        u64 *done_g = h->d_done + (size_t)g0 * 4;
-        u64 *conv_g = h->d_conv + (size_t)g0 * 4;
-        u64 *unsat_g = h->d_unsat + (size_t)g0 * 4;
+        const u64 *synd_g = h->d_synd + (size_t)g0 * h->m;
+        u64 *hard_g = h->d_hard + (size_t)g0 * h->n;
+        u64 *done_g = h->d_done + g0;
+        u64 *conv_g = h->d_conv + g0;
+        u64 *unsat_g = h->d_unsat + g0;
         int *iters_g = h->d_iters + (size_t)g0 * TW;
         float *post_g = out_llr ? h->d_post + (size_t)g0 * h->n * TW : nullptr;
         if (h->E) {
-            hipLaunchKernelGGL(k_init_v2c, dim3((unsigned)((h->E + 3) / 4), g), dim3(256), 0, s, h->d_col_idx,
-                               h->d_prior, (float4 *)h->d_v2c, h->E);
+            hipLaunchKernelGGL(k_init_msg, dim3((unsigned)((h->E + 3) / 4), g), dim3(256), 0, s, h->d_col_idx,
+                               h->d_prior, h->d_msg, h->E);
             LAUNCH_CHECK();
         }
         if (early) SC_HIP(hipMemsetAsync(h->d_remaining, 0, sizeof(int) * ((size_t)max_iter + 2), s));
         for (int it = 1; it <= max_iter; it++) {
             const bool last = it == max_iter;
-            SC_TRY(launch_check(h, method, alpha_for(alpha, it), g, synd_g, s));
-            SC_TRY(launch_var(h, g, post_g, hard_g, done_g, (early || last) ? 1 : 0, s));
+            SC_TRY(launch_check(h, method, alpha_for(alpha, it), g, synd_g, done_g, skip, s));
+            SC_TRY(launch_var(h, g, post_g, hard_g, done_g, skip, (early || last) ? 1 : 0, s));
             if (early || last) {
                 hipLaunchKernelGGL(k_parity<true>, dim3((h->m + 255) / 256, g), dim3(256), 0, s, h->d_row_ptr,
-                                   h->d_col_idx, hard_g, h->m, h->n, const_cast<u64 *>(synd_g), unsat_g);
+                                   h->d_col_idx, hard_g, h->m, h->n, const_cast<u64 *>(synd_g), unsat_g,
+                                   (const u64 *)done_g);
                 LAUNCH_CHECK();
-                hipLaunchKernelGGL(k_finalize, dim3(g), dim3(256), 0, s, it, early ? 1 : 0, done_g, conv_g, unsat_g,
+                hipLaunchKernelGGL(k_finalize, dim3(g), dim3(64), 0, s, it, early ? 1 : 0, done_g, conv_g, unsat_g,
                                    iters_g, h->d_remaining + it);
                 LAUNCH_CHECK();
             }
@@ -956,16 +918,15 @@ int scaldpc_bp_decode_batch(scaldpc_bp *h, const uint8_t *in, int32_t input_kind
         diters = out_iters ? h->d_out_iters : nullptr;
         dconv = out_conv ? h->d_out_conv : nullptr;
     }
-    hipLaunchKernelGGL(k_unpack_bits, dim3((h->n + 255) / 256, batch), dim3(256), 0, s, h->d_hard,
-                       input_kind == SCALDPC_IN_RECEIVED ? h->d_recv : (const u64 *)nullptr, h->n, dbits);
+    hipLaunchKernelGGL(k_unpack_bits, dim3((h->n + 255) / 256, T), dim3(256), 0, s, h->d_hard,
+                       input_kind == SCALDPC_IN_RECEIVED ? h->d_recv : (const u64 *)nullptr, h->n, batch, dbits);
     LAUNCH_CHECK();
     if (out_llr) {
-        hipLaunchKernelGGL(k_unpack_llr, dim3((h->n + 31) / 32, TW / 32, T), dim3(32, 8), 0, s, h->d_post, h->n, batch,
-                           dllr);
+        hipLaunchKernelGGL(k_unpack_llr, dim3((h->n + 63) / 64, T), dim3(256), 0, s, h->d_post, h->n, batch, dllr);
         LAUNCH_CHECK();
     }
     if (diters || dconv) {
-        hipLaunchKernelGGL(k_unpack_state, dim3(T), dim3(256), 0, s, h->d_conv, h->d_iters, batch, diters, dconv);
+        hipLaunchKernelGGL(k_unpack_state, dim3(T), dim3(64), 0, s, h->d_conv, h->d_iters, batch, diters, dconv);
         LAUNCH_CHECK();
     }
     if (!dev_io) {
@@ -991,9 +952,9 @@ int scaldpc_bp_time_kernels(scaldpc_bp *h, int32_t iters, int32_t method, float 
     int rc = 0;
     for (int it = 0; it < iters && !rc; it++) {
         SC_HIP(hipEventRecord(ev[3 * it + 0], s));
-        rc = launch_check(h, method, alpha_for(alpha, it + 1), g, h->d_synd, s);
+        rc = launch_check(h, method, alpha_for(alpha, it + 1), g, h->d_synd, h->d_done, 0, s);
         SC_HIP(hipEventRecord(ev[3 * it + 1], s));
-        if (!rc) rc = launch_var(h, g, nullptr, h->d_hard, h->d_done, 0, s);
+        if (!rc) rc = launch_var(h, g, nullptr, h->d_hard, h->d_done, 0, 0, s);
         SC_HIP(hipEventRecord(ev[3 * it + 2], s));
     }
     if (!rc) {
@@ -1006,9 +967,9 @@ int scaldpc_bp_time_kernels(scaldpc_bp *h, int32_t iters, int32_t method, float 
             ms[0] += a;
             ms[1] += b;
         }
-        launches[0] = iters * (method == SCALDPC_BP_MIN_SUM ? 1 : (int)h->row_buckets.size());
-        launches[1] = iters * (int)h->var_buckets.size();
-        launches[2] = g * TW;  // codewords swept per pass
+        launches[0] = iters;
+        launches[1] = iters;
+        launches[2] = g * TW;  // codewords swept per launch
     }
     for (auto &e : ev) (void)hipEventDestroy(e);
     return rc;
@@ -1019,7 +980,7 @@ void scaldpc_bp_destroy(scaldpc_bp *h)
     if (!h) return;
     dev_free(h->d_row_ptr); dev_free(h->d_col_idx); dev_free(h->d_col_ptr); dev_free(h->d_csc_edge);
     dev_free(h->d_var_list); dev_free(h->d_row_list); dev_free(h->d_prior);
-    dev_free(h->d_v2c); dev_free(h->d_c2v); dev_free(h->d_post);
+    dev_free(h->d_msg); dev_free(h->d_scratch); dev_free(h->d_post);
     dev_free(h->d_synd); dev_free(h->d_recv); dev_free(h->d_hard); dev_free(h->d_done);
     dev_free(h->d_conv); dev_free(h->d_unsat); dev_free(h->d_iters); dev_free(h->d_remaining);
     dev_free(h->d_in); dev_free(h->d_out_bits); dev_free(h->d_out_conv); dev_free(h->d_out_llr);

@@ -72,11 +72,14 @@ def test_alpha_schedule(oracle):
 
 @pytest.mark.parametrize("method", ["min_sum", "product_sum"])
 def test_wide_rows_and_columns(oracle, method):
-    """row degree > 64 (sign-mask path off / generic tanh) and column degree > 32 (generic var)."""
+    """row degree > 64 (sign-mask path off / generic tanh), column degree > 64 (generic var),
+    plus the 33..64 register buckets, a degree-1 row and an isolated variable."""
     rng = np.random.RandomState(5)
-    H = (rng.rand(50, 200) < 0.05).astype(np.int8)
+    H = (rng.rand(90, 200) < 0.04).astype(np.int8)
     H[0, :100] = 1  # row of degree >= 100
-    H[:40, 3] = 1  # column of degree >= 40
+    H[2, 100:150] = 1  # row of degree ~50
+    H[:80, 3] = 1  # column of degree >= 80
+    H[:40, 5] = 1  # column of degree ~40
     H[1, :] = 0
     H[1, 7] = 1  # degree-1 row
     H[:, 150] = 0  # isolated variable
