@@ -55,8 +55,6 @@ def _declare(lib):
         "scaldpc_bp_decode_batch", "scaldpc_bp_time_kernels", "scaldpc_bp_set_tile_group",
     ):  # fmt: skip
         getattr(lib, name).restype = C.c_int
-    if not hasattr(lib, "scaldpc_qary_create"):  # TODO(q-ary): remove once scaldpc_qary.hip lands
-        return
     lib.scaldpc_qary_create.argtypes = [C.c_int32, C.c_int32, C.c_int32, vp, C.c_int32, p(vp)]
     lib.scaldpc_qary_min_sum_batch.argtypes = [vp, vp, C.c_int32, C.c_uint32, vp, vp]
     lib.scaldpc_qary_destroy.argtypes = [vp]

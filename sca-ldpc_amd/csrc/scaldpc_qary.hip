@@ -1,2 +1,566 @@
-// placeholder translation unit; q-ary kernels follow
+// libscaldpc -- q-ary min-sum decoders on MI355X (gfx950).
+//
+// Replaces the in-tree Rust decoders of the reference's `simulate_rs` crate
+// (simulate-with-python/simulate_rs/src/):
+//   Decoder::new / min_sum / into_llr        decoder.rs:494-553, 560-666, 668-692
+//   DecoderSpecial::new / min_sum            decoder_special.rs:387-464, 471-617
+// reached from Python through pydecoder.rs:24-65 / 96-145.
+//
+// Arithmetic is the reference's, in its order, in f32: per check the minimum over all
+// assignments d with sum d = 0 (over the integers) of S - alpha_j[d_j], S summed left to
+// right from 0.0 exactly as `.sum()` does (decoder.rs:600-610); per variable channel +
+// sum(c2v * h), minus self, normalised by the first minimum (decoder.rs:634-652); hard
+// decision = first argmin of the total at the last iteration.  Minima are exact, so the
+// order in which assignments are enumerated does not matter; everything else is
+// add/subtract in the reference's order => hard decisions bit-exact with the oracle.
+//
+// Parallelisation: lane = codeword (batch innermost), thread = (node, codeword).
+//   msg : float [edge][W][Bp]     one array, updated in place (v2c <-> c2v)
+//   llr : float [var][Q][Bp]
+// The enumeration indexes the alphabet with per-lane run-time digits, which rules out
+// registers; per-thread alpha / beta vectors are staged in LDS laid out [slot][thread],
+// so that whatever slot each lane picks, lane l always hits bank l (conflict free).
+// This path is ALU/LDS bound (Q^(DC-1) assignments per check), not HBM bound; no
+// roofline claim is made for it.
 #include "scaldpc_common.h"
+
+#include <cmath>
+#include <cstring>
+#include <mutex>
+#include <vector>
+
+using namespace scaldpc;
+typedef unsigned long long u64;
+
+namespace {
+
+constexpr int QERR_NO_FINITE = 5;  // decoder.rs:368-375 would spin forever
+constexpr int QERR_NO_CONFIG = 6;  // decoder.rs:618 assert
+constexpr int QERR_PMF = 3;        // decoder.rs:683-684 assert
+
+__device__ __forceinline__ bool finite_f(float x) { return fabsf(x) < INFINITY; }  // false for inf and NaN
+
+// decoder.rs:668-692 on the device (DEVICE_IO path; the host path converts with glibc so
+// that LLRs are bit-identical to the oracle's).  pmf: [batch][nv][Q] -> llr [nv][Q][Bp].
+__global__ void k_q_into_llr(const float *__restrict__ pmf, int nv, int Q, int batch, long Bp,
+                             float *__restrict__ llr, int *__restrict__ err)
+{
+    const long b = (long)blockIdx.y * blockDim.x + threadIdx.x;
+    const int v = blockIdx.x;
+    if (b >= Bp) return;
+    if (b >= batch) {  // padding lanes decode a harmless all-equal message
+        for (int q = 0; q < Q; q++) llr[((size_t)v * Q + q) * Bp + b] = 0.0f;
+        return;
+    }
+    const float *p = pmf + ((size_t)b * nv + v) * Q;
+    float sum = 0.0f, mx = 0.0f;
+    bool have = false;
+    for (int q = 0; q < Q; q++) {
+        sum += p[q];
+        if (p[q] == p[q] && (!have || p[q] > mx)) {
+            mx = p[q];
+            have = true;
+        }
+    }
+    if (!have || !(sum < 1.0f + 0.001f) || !(sum > 1.0f - 0.001f)) atomicMax(err, QERR_PMF);
+    for (int q = 0; q < Q; q++) llr[((size_t)v * Q + q) * Bp + b] = logf(mx / p[q]);
+}
+
+// decoder.rs:567-573: v2c = channel * h.  thread = (edge, codeword).
+__global__ void k_q_init(const int *__restrict__ edge_var, const int *__restrict__ edge_h,
+                         const int *__restrict__ var_q, const long *__restrict__ var_off,
+                         const float *__restrict__ llr, float *__restrict__ msg, int W, long Bp)
+{
+    const long b = (long)blockIdx.y * blockDim.x + threadIdx.x;
+    const int e = blockIdx.x;
+    if (b >= Bp) return;
+    const int v = edge_var[e], Q = var_q[v];
+    const float *ch = llr + var_off[v] * Bp + b;
+    const bool rev = edge_h[e] < 0;
+    for (int q = 0; q < Q; q++) msg[((size_t)e * W + q) * Bp + b] = ch[(size_t)(rev ? Q - 1 - q : q) * Bp];
+}
+
+// Check-node update of Decoder (decoder.rs:585-631), finite-support enumeration
+// (FiniteDValueIterator, decoder.rs:281-401), index 0 fastest.
+// block = T threads = T codewords of one check; LDS: A[k*Q][T], Bt[k*Q][T] floats, fin[k*Q][T] bytes.
+__global__ void k_q_check(const int *__restrict__ row_ptr, float *msg, int Q, int B, long Bp, int batch, int maxdc,
+                          int *__restrict__ err)
+{
+    extern __shared__ unsigned char smem[];
+    const int T = blockDim.x, tid = threadIdx.x;
+    float *A = (float *)smem;
+    float *Bt = A + (size_t)maxdc * Q * T;
+    unsigned char *fin = (unsigned char *)(Bt + (size_t)maxdc * Q * T);
+    const int c = blockIdx.x;
+    const long b = (long)blockIdx.y * T + tid;
+    if (b >= batch) return;  // padding lanes: no barrier below, every thread owns its LDS column
+    const int e0 = row_ptr[c], k = row_ptr[c + 1] - e0;
+    if (k == 0) {
+        if (tid == 0) atomicMax(err, QERR_NO_CONFIG);
+        return;
+    }
+    u64 nums = 0;
+    bool bad = false;
+    for (int j = 0; j < k; j++) {
+        int cnt = 0;
+        for (int q = 0; q < Q; q++) {
+            const float x = msg[((size_t)(e0 + j) * Q + q) * Bp + b];
+            A[(size_t)(j * Q + q) * T + tid] = x;
+            Bt[(size_t)(j * Q + q) * T + tid] = INFINITY;
+            if (finite_f(x)) fin[(size_t)(j * Q + cnt++) * T + tid] = (unsigned char)q;
+        }
+        nums |= (u64)cnt << (8 * j);
+        bad |= cnt == 0;
+    }
+    if (bad) {
+        atomicMax(err, QERR_NO_FINITE);
+    } else {
+        u64 idx = 0;
+        int nconf = 0;
+        for (;;) {
+            int dsum = 0;
+            float S = 0.0f;
+            u64 qs = 0;
+            for (int j = 0; j < k - 1; j++) {
+                const int ij = (int)(idx >> (8 * j)) & 255;
+                const int q = fin[(size_t)(j * Q + ij) * T + tid];
+                qs |= (u64)q << (8 * j);
+                dsum += q - B;
+                S += A[(size_t)(j * Q + q) * T + tid];
+            }
+            const int dl = -dsum;
+            if (dl >= -B && dl <= B) {
+                const int ql = dl + B;
+                qs |= (u64)ql << (8 * (k - 1));
+                S += A[(size_t)((k - 1) * Q + ql) * T + tid];
+                if (finite_f(S)) {
+                    nconf++;
+                    for (int j = 0; j < k; j++) {
+                        const int q = (int)(qs >> (8 * j)) & 255;
+                        const size_t o = (size_t)(j * Q + q) * T + tid;
+                        Bt[o] = fminf(S - A[o], Bt[o]);
+                    }
+                }
+            }
+            int j = 0;
+            for (; j < k - 1; j++) {
+                const int ij = (int)(idx >> (8 * j)) & 255, nj = (int)(nums >> (8 * j)) & 255;
+                if (ij + 1 < nj) {
+                    idx += 1ull << (8 * j);
+                    break;
+                }
+                idx &= ~(255ull << (8 * j));
+            }
+            if (j >= k - 1) break;
+        }
+        if (nconf == 0) atomicMax(err, QERR_NO_CONFIG);
+    }
+    for (int j = 0; j < k; j++)
+        for (int q = 0; q < Q; q++)
+            msg[((size_t)(e0 + j) * Q + q) * Bp + b] = Bt[(size_t)(j * Q + q) * T + tid];
+}
+
+// Check-node update of DecoderSpecial (decoder_special.rs:506-563): the first k-1 edges
+// are B-variables (alphabet QB), the last is the row-sum variable (alphabet QS); ALL
+// (2B+1)^(k-1) assignments are visited (SimpleDValueIterator, :226-275), no finiteness
+// filter; f32::min semantics (NaN ignored) = fminf.
+// LDS: Ab[nbm*QB][T], As[QS][T], Bb[nbm*QB][T], Bs[QS][T].
+__global__ void k_q_special_check(const int *__restrict__ row_ptr, float *msg, int B, int BSUM, int W, long Bp,
+                                  int batch, int nbm)
+{
+    extern __shared__ unsigned char smem[];
+    const int T = blockDim.x, tid = threadIdx.x;
+    const int QB = 2 * B + 1, QS = 2 * BSUM + 1;
+    float *Ab = (float *)smem;
+    float *As = Ab + (size_t)nbm * QB * T;
+    float *Bb = As + (size_t)QS * T;
+    float *Bs = Bb + (size_t)nbm * QB * T;
+    const int c = blockIdx.x;
+    const long b = (long)blockIdx.y * T + tid;
+    if (b >= batch) return;
+    const int e0 = row_ptr[c], k = row_ptr[c + 1] - e0, nb = k - 1;
+    for (int j = 0; j < nb; j++)
+        for (int q = 0; q < QB; q++) {
+            Ab[(size_t)(j * QB + q) * T + tid] = msg[((size_t)(e0 + j) * W + q) * Bp + b];
+            Bb[(size_t)(j * QB + q) * T + tid] = INFINITY;
+        }
+    for (int q = 0; q < QS; q++) {
+        As[(size_t)q * T + tid] = msg[((size_t)(e0 + nb) * W + q) * Bp + b];
+        Bs[(size_t)q * T + tid] = INFINITY;
+    }
+    u64 dq = 0;  // digit j = d_j + B, 8 bits each, all start at 0 (= -B)
+    for (;;) {
+        int dsum = 0;
+        float S = 0.0f;
+        for (int j = 0; j < nb; j++) {
+            const int q = (int)(dq >> (8 * j)) & 255;
+            dsum += q - B;
+            S += Ab[(size_t)(j * QB + q) * T + tid];
+        }
+        const size_t os = (size_t)(-dsum + BSUM) * T + tid;
+        S += As[os];
+        for (int j = 0; j < nb; j++) {
+            const int q = (int)(dq >> (8 * j)) & 255;
+            const size_t o = (size_t)(j * QB + q) * T + tid;
+            Bb[o] = fminf(Bb[o], S - Ab[o]);
+        }
+        Bs[os] = fminf(Bs[os], S - As[os]);
+        int j = 0;
+        for (; j < nb; j++) {
+            const int q = (int)(dq >> (8 * j)) & 255;
+            if (q < 2 * B) {
+                dq += 1ull << (8 * j);
+                break;
+            }
+            dq &= ~(255ull << (8 * j));
+        }
+        if (j >= nb) break;
+    }
+    for (int j = 0; j < nb; j++)
+        for (int q = 0; q < QB; q++) msg[((size_t)(e0 + j) * W + q) * Bp + b] = Bb[(size_t)(j * QB + q) * T + tid];
+    for (int q = 0; q < QS; q++) msg[((size_t)(e0 + nb) * W + q) * Bp + b] = Bs[(size_t)q * T + tid];
+}
+
+// Variable-node update (decoder.rs:634-658 / decoder_special.rs:566-609).
+// thread = (variable, codeword); LDS: sum[Qmax][T], tmp[Qmax][T].
+__global__ void k_q_var(int v0, const int *__restrict__ col_ptr, const int *__restrict__ csc_edge,
+                        const int *__restrict__ edge_h, const int *__restrict__ var_q,
+                        const long *__restrict__ var_off, const float *__restrict__ llr, float *msg, int W, long Bp,
+                        int batch, int Qmax, int last, signed char *__restrict__ out)
+{
+    extern __shared__ unsigned char smem[];
+    const int T = blockDim.x, tid = threadIdx.x;
+    float *sum = (float *)smem;
+    float *tmp = sum + (size_t)Qmax * T;
+    const int v = v0 + blockIdx.x;
+    const long b = (long)blockIdx.y * T + tid;
+    if (b >= batch) return;
+    const int Q = var_q[v], Bv = (Q - 1) / 2;
+    const float *ch = llr + var_off[v] * Bp + b;
+    for (int q = 0; q < Q; q++) sum[(size_t)q * T + tid] = ch[(size_t)q * Bp];
+    const int c0 = col_ptr[v], c1 = col_ptr[v + 1];
+    for (int t = c0; t < c1; t++) {
+        const int e = csc_edge[t];
+        const bool rev = edge_h[e] < 0;
+        const float *in = msg + (size_t)e * W * Bp + b;
+        for (int q = 0; q < Q; q++) sum[(size_t)q * T + tid] = sum[(size_t)q * T + tid] + in[(size_t)(rev ? Q - 1 - q : q) * Bp];
+    }
+    for (int t = c0; t < c1; t++) {
+        const int e = csc_edge[t];
+        const bool rev = edge_h[e] < 0;
+        float *io = msg + (size_t)e * W * Bp + b;
+        // prim_out = (sum - c2v*h) * h   (qary_sub_with_mult_in_gf then mult_in_gf)
+        for (int q = 0; q < Q; q++) {
+            const int qi = rev ? Q - 1 - q : q;
+            tmp[(size_t)qi * T + tid] = sum[(size_t)q * T + tid] - io[(size_t)qi * Bp];
+        }
+        float mv = INFINITY;
+        int ma = 0;
+        for (int q = 0; q < Q; q++) {
+            const float x = tmp[(size_t)q * T + tid];
+            if (x < mv) {
+                mv = x;
+                ma = q;
+            }
+        }
+        const float mn = tmp[(size_t)ma * T + tid];
+        for (int q = 0; q < Q; q++) io[(size_t)q * Bp] = tmp[(size_t)q * T + tid] - mn;
+    }
+    if (last) {
+        float mv = INFINITY;
+        int ma = 0;
+        for (int q = 0; q < Q; q++) {
+            const float x = sum[(size_t)q * T + tid];
+            if (x < mv) {
+                mv = x;
+                ma = q;
+            }
+        }
+        out[(size_t)v * Bp + b] = (signed char)(ma - Bv);
+    }
+}
+
+// [N][Bp] -> [batch][N]
+__global__ void k_q_unpack(const signed char *__restrict__ in, int N, int batch, long Bp, signed char *__restrict__ out)
+{
+    const int v = blockIdx.x * blockDim.x + threadIdx.x;
+    const int b = blockIdx.y;
+    if (v < N && b < batch) out[(size_t)b * N + v] = in[(size_t)v * Bp + b];
+}
+
+}  // namespace
+
+struct scaldpc_qary {
+    bool special = false;
+    int R = 0, N = 0, B = 0, BSUM = 0, Q = 0, QS = 0, W = 0, iterations = 0;
+    int E = 0, maxdc = 0;
+    long llr_rows = 0;  // total alphabet rows over all variables
+    int *d_row_ptr = nullptr, *d_col_ptr = nullptr, *d_csc_edge = nullptr, *d_edge_var = nullptr, *d_edge_h = nullptr,
+        *d_var_q = nullptr;
+    long *d_var_off = nullptr;
+    std::vector<int> h_var_q;
+    std::vector<long> h_var_off;
+    long cap_bp = 0;
+    float *d_msg = nullptr, *d_llr = nullptr, *d_pmf = nullptr, *d_pmf2 = nullptr;
+    signed char *d_hard = nullptr, *d_out = nullptr;
+    size_t cap_pmf = 0, cap_pmf2 = 0, cap_out = 0;
+    int *d_err = nullptr;
+    hipStream_t own_stream = nullptr;
+    std::mutex mu;
+};
+
+namespace {
+
+int qary_build(int R, int N, int B, int BSUM, bool special, const int8_t *H, int iterations, scaldpc_qary **out)
+{
+    if (!out) return fail(SCALDPC_EINVAL, "out is NULL");
+    *out = nullptr;
+    if (R <= 0 || N <= 0 || B < 1 || !H || iterations < 0)
+        return fail(SCALDPC_EINVAL, "bad q-ary decoder arguments (R=%d N=%d B=%d)", R, N, B);
+    if (B > 127) return fail(SCALDPC_EDEGREE, "B=%d: hard decisions are int8 (decoder.rs i8)", B);
+    if (special) {
+        if (BSUM < 1 || BSUM % B != 0)
+            return fail(SCALDPC_EINVAL, "BSUM (%d) must be multiple of B (%d)", BSUM, B);  // decoder_special.rs:388-392
+        if (N <= R) return fail(SCALDPC_EINVAL, "special decoder needs N > R");
+        if (BSUM > 127) return fail(SCALDPC_EDEGREE, "BSUM=%d: hard decisions are int8", BSUM);
+    }
+    const int BV = special ? N - R : N;
+    std::vector<int> row_ptr(R + 1, 0), col_cnt(N, 0), edge_var, edge_h;
+    for (int r = 0; r < R; r++) {
+        for (int c = 0; c < N; c++) {
+            const int h = H[(size_t)r * N + c];
+            if (!h) continue;
+            if (h != 1 && h != -1) return fail(SCALDPC_EINVAL, "H[%d][%d] = %d: entries must be in {-1,0,1}", r, c, h);
+            edge_var.push_back(c);
+            edge_h.push_back(h);
+            col_cnt[c]++;
+        }
+        row_ptr[r + 1] = (int)edge_var.size();
+    }
+    const int E = (int)edge_var.size();
+    int maxdc = 0;
+    for (int r = 0; r < R; r++) maxdc = std::max(maxdc, row_ptr[r + 1] - row_ptr[r]);
+    if (maxdc > 8) return fail(SCALDPC_EDEGREE, "check degree %d > 8 is not supported by the enumeration kernel", maxdc);
+    if (special) {
+        for (int r = 0; r < R; r++) {
+            const int k = row_ptr[r + 1] - row_ptr[r];
+            if (k < 1) return fail(SCALDPC_EINVAL, "special decoder: check %d is empty", r);
+            for (int j = 0; j < k - 1; j++)
+                if (edge_var[row_ptr[r] + j] >= BV)
+                    return fail(SCALDPC_EINVAL, "special decoder: H is not of the form [H' | I] (row %d)", r);
+            if (edge_var[row_ptr[r] + k - 1] < BV)
+                return fail(SCALDPC_EINVAL, "special decoder: row %d has no row-sum variable (H != [H' | I])", r);
+            if ((k - 1) * B > BSUM)
+                return fail(SCALDPC_EINVAL, "special decoder: (degree-1)*B = %d exceeds BSUM = %d in row %d", (k - 1) * B,
+                            BSUM, r);
+        }
+        for (int v = BV; v < N; v++)
+            if (col_cnt[v] != 1) return fail(SCALDPC_EINVAL, "special decoder: row-sum variable %d has degree %d", v, col_cnt[v]);
+    }
+    std::vector<int> col_ptr(N + 1, 0), csc_edge(E), fill(N, 0);
+    for (int v = 0; v < N; v++) col_ptr[v + 1] = col_ptr[v] + col_cnt[v];
+    for (int e = 0; e < E; e++) csc_edge[col_ptr[edge_var[e]] + fill[edge_var[e]]++] = e;
+
+    scaldpc_qary *h = new (std::nothrow) scaldpc_qary();
+    if (!h) return fail(SCALDPC_ENOMEM, "out of host memory");
+    h->special = special;
+    h->R = R; h->N = N; h->B = B; h->BSUM = BSUM;
+    h->Q = 2 * B + 1;
+    h->QS = special ? 2 * BSUM + 1 : h->Q;
+    h->W = std::max(h->Q, h->QS);
+    h->iterations = iterations;
+    h->E = E;
+    h->maxdc = maxdc;
+    h->h_var_q.resize(N);
+    h->h_var_off.resize(N);
+    long off = 0;
+    for (int v = 0; v < N; v++) {
+        h->h_var_q[v] = v < BV ? h->Q : h->QS;
+        h->h_var_off[v] = off;
+        off += h->h_var_q[v];
+    }
+    h->llr_rows = off;
+    int rc = 0;
+    auto up = [&](int **d, const int *src, size_t cnt) -> int {
+        SC_TRY(dev_alloc(d, cnt));
+        if (cnt) SC_HIP(hipMemcpy(*d, src, cnt * sizeof(int), hipMemcpyHostToDevice));
+        return 0;
+    };
+    if (!rc) rc = up(&h->d_row_ptr, row_ptr.data(), R + 1);
+    if (!rc) rc = up(&h->d_col_ptr, col_ptr.data(), N + 1);
+    if (!rc) rc = up(&h->d_csc_edge, csc_edge.data(), E);
+    if (!rc) rc = up(&h->d_edge_var, edge_var.data(), E);
+    if (!rc) rc = up(&h->d_edge_h, edge_h.data(), E);
+    if (!rc) rc = up(&h->d_var_q, h->h_var_q.data(), N);
+    if (!rc) rc = dev_alloc(&h->d_var_off, (size_t)N);
+    if (!rc && hipMemcpy(h->d_var_off, h->h_var_off.data(), sizeof(long) * N, hipMemcpyHostToDevice) != hipSuccess)
+        rc = fail(SCALDPC_EHIP, "hipMemcpy failed");
+    if (!rc) rc = dev_alloc(&h->d_err, 1);
+    if (!rc && hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking) != hipSuccess)
+        rc = fail(SCALDPC_EHIP, "hipStreamCreate failed");
+    if (rc) {
+        scaldpc_qary_destroy(h);
+        return rc;
+    }
+    *out = h;
+    return 0;
+}
+
+template <typename T>
+int growq(T **p, size_t *cap, size_t need)
+{
+    if (need <= *cap && *p) return 0;
+    dev_free(*p);
+    *cap = 0;
+    SC_TRY(dev_alloc(p, need));
+    *cap = need;
+    return 0;
+}
+
+// decoder.rs:668-692 on the host with glibc logf -- bit-identical to the oracle.
+int host_into_llr(const float *pmf, int batch, int nv, int Q, long Bp, long row0, std::vector<float> &llr)
+{
+    for (int b = 0; b < batch; b++)
+        for (int v = 0; v < nv; v++) {
+            const float *p = pmf + ((size_t)b * nv + v) * Q;
+            float sum = 0.0f, mx = 0.0f;
+            bool have = false;
+            for (int q = 0; q < Q; q++) {
+                sum += p[q];
+                if (p[q] == p[q] && (!have || p[q] > mx)) {
+                    mx = p[q];
+                    have = true;
+                }
+            }
+            if (!have) return fail(SCALDPC_EPMF, "No maximum probability found (codeword %d, variable %d)", b, v);
+            if (!(sum < 1.0f + 0.001f) || !(sum > 1.0f - 0.001f))
+                return fail(SCALDPC_EPMF, "channel output of codeword %d, variable %d sums to %g, not 1 +- 1e-3", b, v,
+                            (double)sum);
+            for (int q = 0; q < Q; q++) llr[((size_t)(row0 + (long)v * Q + q)) * Bp + b] = logf(mx / p[q]);
+        }
+    return 0;
+}
+
+int qary_run(scaldpc_qary *h, const float *pmf_b, const float *pmf_s, int batch, uint32_t flags, void *stream,
+             int8_t *out)
+{
+    if (!h || !pmf_b || !out || (h->special && !pmf_s)) return fail(SCALDPC_EINVAL, "NULL argument");
+    if (batch <= 0) return fail(SCALDPC_EINVAL, "batch must be positive");
+    std::lock_guard<std::mutex> lk(h->mu);
+    const bool dev_io = flags & SCALDPC_F_DEVICE_IO;
+    hipStream_t s = stream ? (hipStream_t)stream : h->own_stream;
+    const long Bp = ((long)batch + 63) / 64 * 64;
+    const int BV = h->special ? h->N - h->R : h->N;
+    if (Bp > h->cap_bp) {
+        dev_free(h->d_msg); dev_free(h->d_llr); dev_free(h->d_hard);
+        h->cap_bp = 0;
+        SC_TRY(dev_alloc(&h->d_msg, (size_t)std::max(h->E, 1) * h->W * Bp));
+        SC_TRY(dev_alloc(&h->d_llr, (size_t)h->llr_rows * Bp));
+        SC_TRY(dev_alloc(&h->d_hard, (size_t)h->N * Bp));
+        h->cap_bp = Bp;
+    }
+    SC_HIP(hipMemsetAsync(h->d_err, 0, sizeof(int), s));
+    const int TB = 64;
+    if (!dev_io) {
+        std::vector<float> llr((size_t)h->llr_rows * Bp, 0.0f);  // padding lanes: all-equal messages
+        SC_TRY(host_into_llr(pmf_b, batch, BV, h->Q, Bp, 0, llr));
+        if (h->special) SC_TRY(host_into_llr(pmf_s, batch, h->R, h->QS, Bp, (long)BV * h->Q, llr));
+        SC_HIP(hipMemcpyAsync(h->d_llr, llr.data(), llr.size() * sizeof(float), hipMemcpyHostToDevice, s));
+        SC_HIP(hipStreamSynchronize(s));  // llr is a local
+    } else {
+        hipLaunchKernelGGL(k_q_into_llr, dim3(BV, Bp / TB), dim3(TB), 0, s, pmf_b, BV, h->Q, batch, Bp, h->d_llr,
+                           h->d_err);
+        SC_HIP(hipGetLastError());
+        if (h->special) {
+            hipLaunchKernelGGL(k_q_into_llr, dim3(h->R, Bp / TB), dim3(TB), 0, s, pmf_s, h->R, h->QS, batch, Bp,
+                               h->d_llr + (size_t)BV * h->Q * Bp, h->d_err);
+            SC_HIP(hipGetLastError());
+        }
+    }
+    if (h->E) {
+        hipLaunchKernelGGL(k_q_init, dim3(h->E, Bp / TB), dim3(TB), 0, s, h->d_edge_var, h->d_edge_h, h->d_var_q,
+                           h->d_var_off, h->d_llr, h->d_msg, h->W, Bp);
+        SC_HIP(hipGetLastError());
+    }
+    // threads per block of the enumeration kernels: as many (<= 64) as fit 64 KB of LDS
+    size_t per_thread = h->special ? (size_t)2 * ((h->maxdc - 1) * h->Q + h->QS) * 4 : (size_t)h->maxdc * h->Q * 9;
+    int T = 64;
+    while (T > 8 && per_thread * T > 64 * 1024) T >>= 1;
+    if (per_thread * T > 64 * 1024)
+        return fail(SCALDPC_EDEGREE, "alphabet/degree too large for the LDS-staged enumeration (%zu B per codeword)",
+                    per_thread);
+    const int iters = std::max(1, h->iterations);  // the loop body runs at least once (decoder.rs:578-579)
+    for (int it = 1; it <= iters; it++) {
+        if (h->E) {
+            if (h->special)
+                hipLaunchKernelGGL(k_q_special_check, dim3(h->R, Bp / T), dim3(T), per_thread * T, s, h->d_row_ptr,
+                                   h->d_msg, h->B, h->BSUM, h->W, Bp, batch, h->maxdc - 1);
+            else
+                hipLaunchKernelGGL(k_q_check, dim3(h->R, Bp / T), dim3(T), per_thread * T, s, h->d_row_ptr, h->d_msg,
+                                   h->Q, h->B, Bp, batch, h->maxdc, h->d_err);
+            SC_HIP(hipGetLastError());
+        }
+        hipLaunchKernelGGL(k_q_var, dim3(h->N, Bp / TB), dim3(TB), (size_t)2 * h->W * TB * 4, s, 0, h->d_col_ptr,
+                           h->d_csc_edge, h->d_edge_h, h->d_var_q, h->d_var_off, h->d_llr, h->d_msg, h->W, Bp, batch, h->W,
+                           it == iters ? 1 : 0, h->d_hard);
+        SC_HIP(hipGetLastError());
+    }
+    signed char *dout = (signed char *)out;
+    if (!dev_io) {
+        SC_TRY(growq(&h->d_out, &h->cap_out, (size_t)batch * h->N));
+        dout = h->d_out;
+    }
+    hipLaunchKernelGGL(k_q_unpack, dim3((h->N + 255) / 256, batch), dim3(256), 0, s, h->d_hard, h->N, batch, Bp, dout);
+    SC_HIP(hipGetLastError());
+    int err = 0;
+    SC_HIP(hipMemcpyAsync(&err, h->d_err, sizeof(int), hipMemcpyDeviceToHost, s));
+    if (!dev_io) SC_HIP(hipMemcpyAsync(out, dout, (size_t)batch * h->N, hipMemcpyDeviceToHost, s));
+    SC_HIP(hipStreamSynchronize(s));
+    if (err == QERR_PMF) return fail(SCALDPC_EPMF, "a channel-output row does not sum to 1 +- 1e-3 (decoder.rs:683-684)");
+    if (err == QERR_NO_CONFIG)
+        return fail(SCALDPC_ENOCONF, "a check node admits no finite configuration (decoder.rs:618)");
+    if (err == QERR_NO_FINITE)
+        return fail(SCALDPC_ENOCONF, "a message has no finite entry (the reference would not terminate, decoder.rs:368-375)");
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int scaldpc_qary_create(int32_t R, int32_t N, int32_t B, const int8_t *H, int32_t iterations, scaldpc_qary **out)
+{
+    return qary_build(R, N, B, 0, false, H, iterations, out);
+}
+
+int scaldpc_qary_special_create(int32_t R, int32_t N, int32_t B, int32_t BSUM, const int8_t *H, int32_t iterations,
+                                scaldpc_qary **out)
+{
+    return qary_build(R, N, B, BSUM, true, H, iterations, out);
+}
+
+int scaldpc_qary_min_sum_batch(scaldpc_qary *h, const float *pmf, int32_t batch, uint32_t flags, void *stream,
+                               int8_t *out)
+{
+    if (h && h->special) return fail(SCALDPC_EINVAL, "this handle is a special decoder: use scaldpc_qary_special_min_sum_batch");
+    return qary_run(h, pmf, nullptr, batch, flags, stream, out);
+}
+
+int scaldpc_qary_special_min_sum_batch(scaldpc_qary *h, const float *pmf_b, const float *pmf_sum, int32_t batch,
+                                       uint32_t flags, void *stream, int8_t *out)
+{
+    if (h && !h->special) return fail(SCALDPC_EINVAL, "this handle is not a special decoder");
+    return qary_run(h, pmf_b, pmf_sum, batch, flags, stream, out);
+}
+
+void scaldpc_qary_destroy(scaldpc_qary *h)
+{
+    if (!h) return;
+    dev_free(h->d_row_ptr); dev_free(h->d_col_ptr); dev_free(h->d_csc_edge); dev_free(h->d_edge_var);
+    dev_free(h->d_edge_h); dev_free(h->d_var_q); dev_free(h->d_var_off); dev_free(h->d_msg); dev_free(h->d_llr);
+    dev_free(h->d_pmf); dev_free(h->d_pmf2); dev_free(h->d_hard); dev_free(h->d_out); dev_free(h->d_err);
+    if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
+    delete h;
+}
+
+}  // extern "C"

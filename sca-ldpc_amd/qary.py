@@ -1,0 +1,146 @@
+"""`simulate_rs`-shaped front end of the HIP q-ary min-sum decoders.
+
+The reference generates one PyO3 class per compile-time size
+(`register_py_decoder_class!`, simulate_rs/src/pydecoder.rs:12-70; sizes listed in
+simulate_rs/src/lib.rs:32-75) and looks them up by name
+(`getattr(simulate_rs, f"DecoderN{n}R{r}V{v}C{c}B{B}")`, simulate/decode.py:227-229).
+Here sizes are run-time values: `decoder_class("DecoderN450R150V3C7B1")` builds a class
+with the same constructor / `min_sum` surface for ANY name of that pattern, plus
+`min_sum_batch` for many channel outputs per call.
+
+  DecoderN{N}R{R}V{DV}C{DC}B{B}(H: int8 [R, N], iterations)   .min_sum(pmf float32 [N, 2B+1]) -> list[int]
+  DecoderN{N}R{R}SW{SW}(H: int8 [R, N], iterations)           .min_sum(pmf [N-R, 5], pmf_sum [R, 2*BSUM+1]) -> list[int]
+      (B = 2, BSUM = SW*B, DC = SW+1: the Kyber decoders of lib.rs:54-75)
+
+Inputs are probabilities; the LLR conversion (decoder.rs:668-692) happens inside, as in
+the reference.  Errors: a pmf row not summing to 1 +- 1e-3 and a check without any
+finite configuration raise (the reference panics); shape mismatches raise ValueError.
+`min_sum` may be called concurrently from many Python threads on one object (the
+reference's thread pool does, decode.py:247-262): calls are serialised in the library
+and ctypes releases the GIL meanwhile.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import re
+
+import numpy as np
+
+from . import _lib
+
+_GENERIC = re.compile(r"^DecoderN(\d+)R(\d+)V(\d+)C(\d+)B(\d+)$")
+_SPECIAL = re.compile(r"^DecoderN(\d+)R(\d+)SW(\d+)$")
+
+
+class _QaryBase:
+    N = R = DV = DC = B = Q = 0
+
+    def _check_H(self, H):
+        H = np.asarray(H)
+        if H.dtype != np.int8:
+            raise TypeError("parity check matrix must have dtype int8 (as PyReadonlyArray2<i8>, pydecoder.rs:24)")
+        if H.shape != (self.R, self.N):
+            raise ValueError(f"parity check matrix has shape {H.shape}, this decoder is built for ({self.R}, {self.N})")
+        nz = H != 0
+        if nz.sum(axis=0).max() > self.DV or nz.sum(axis=1).max() > self.DC:
+            # the reference panics in insert_first_none (decoder.rs:465-473)
+            raise ValueError("Reached the end of the array, no more space left! (node degree exceeds DV/DC)")
+        return np.ascontiguousarray(H)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.scaldpc_qary_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class QaryDecoder(_QaryBase):
+    """Decoder<N, R, DV, DC, Q=2B+1, B, i8> (decoder.rs:417-438)."""
+
+    def __init__(self, py_parity_check, iterations):
+        self._h = None
+        self._lib = _lib.load()
+        H = self._check_H(py_parity_check)
+        h = C.c_void_p()
+        _lib.check(self._lib.scaldpc_qary_create(self.R, self.N, self.B, _lib.ptr(H), int(iterations), C.byref(h)))
+        self._h = h
+
+    def min_sum_batch(self, channel_output):
+        """float32 [batch, N, Q] -> int8 [batch, N]."""
+        p = np.ascontiguousarray(channel_output, dtype=np.float32)
+        if p.ndim != 3 or p.shape[1:] != (self.N, self.Q):
+            raise ValueError(f"channel output has shape {p.shape}, expected (batch, {self.N}, {self.Q})")
+        out = np.empty((p.shape[0], self.N), dtype=np.int8)
+        _lib.check(self._lib.scaldpc_qary_min_sum_batch(self._h, _lib.ptr(p), p.shape[0], 0, None, _lib.ptr(out)))
+        return out
+
+    def min_sum(self, py_channel_output):
+        p = np.asarray(py_channel_output)
+        if p.shape != (self.N, self.Q):
+            raise ValueError(f"channel output has shape {p.shape}, expected ({self.N}, {self.Q})")
+        return [int(x) for x in self.min_sum_batch(p[None])[0]]
+
+
+class QarySpecialDecoder(_QaryBase):
+    """DecoderSpecial<N, R, N-R, DC-1, DC, DV, B, 2B+1, BSUM, 2BSUM+1, i8> (decoder_special.rs:294-322)."""
+
+    BSUM = QS = 0
+
+    def __init__(self, py_parity_check, iterations):
+        self._h = None
+        self._lib = _lib.load()
+        H = self._check_H(py_parity_check)
+        h = C.c_void_p()
+        _lib.check(
+            self._lib.scaldpc_qary_special_create(self.R, self.N, self.B, self.BSUM, _lib.ptr(H), int(iterations), C.byref(h))
+        )
+        self._h = h
+
+    def min_sum_batch(self, channel_output, channel_output_sum):
+        p = np.ascontiguousarray(channel_output, dtype=np.float32)
+        ps = np.ascontiguousarray(channel_output_sum, dtype=np.float32)
+        if p.ndim != 3 or p.shape[1:] != (self.N - self.R, self.Q):
+            raise ValueError(f"channel output has shape {p.shape}, expected (batch, {self.N - self.R}, {self.Q})")
+        if ps.shape != (p.shape[0], self.R, self.QS):
+            raise ValueError(f"channel output sum has shape {ps.shape}, expected ({p.shape[0]}, {self.R}, {self.QS})")
+        out = np.empty((p.shape[0], self.N), dtype=np.int8)
+        _lib.check(
+            self._lib.scaldpc_qary_special_min_sum_batch(self._h, _lib.ptr(p), _lib.ptr(ps), p.shape[0], 0, None, _lib.ptr(out))
+        )
+        return out
+
+    def min_sum(self, py_channel_output, py_channel_output_sum):
+        p, ps = np.asarray(py_channel_output), np.asarray(py_channel_output_sum)
+        if p.ndim != 2 or ps.ndim != 2:
+            raise ValueError("channel outputs must be 2-D")
+        return [int(x) for x in self.min_sum_batch(p[None], ps[None])[0]]
+
+
+_cache = {}
+
+
+def decoder_class(name: str):
+    """Class for a `simulate_rs` decoder name (any size of either pattern)."""
+    if name in _cache:
+        return _cache[name]
+    m = _GENERIC.match(name)
+    if m:
+        N, R, DV, DC, B = map(int, m.groups())
+        cls = type(name, (QaryDecoder,), dict(N=N, R=R, DV=DV, DC=DC, B=B, Q=2 * B + 1))
+    else:
+        m = _SPECIAL.match(name)
+        if not m:
+            raise AttributeError(name)
+        N, R, SW = map(int, m.groups())
+        B = 2  # Kyber eta (lib.rs:54-75: B = 2, BSUM = SW * B)
+        cls = type(
+            name, (QarySpecialDecoder,),
+            dict(N=N, R=R, DV=R, DC=SW + 1, B=B, Q=2 * B + 1, BSUM=SW * B, QS=2 * SW * B + 1),
+        )  # fmt: skip
+    _cache[name] = cls
+    return cls

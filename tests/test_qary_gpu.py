@@ -1,0 +1,156 @@
+"""GPU parity of the q-ary min-sum decoders (through the C ABI) vs the CPU oracle and vs
+the reference's own known-answer tests.  Hard decisions bit-exact."""
+import importlib
+
+import numpy as np
+import pytest
+
+from helpers import S
+
+pytestmark = pytest.mark.gpu
+qary = importlib.import_module("sca-ldpc_amd.qary")
+
+
+def one_bad_symbol(N, Q, B):
+    ch = np.zeros((N, Q), dtype=np.float32)
+    ch[:, B] = 1.0
+    ch[1, B] = 0.1
+    ch[1, B + 7] = 0.9
+    return ch
+
+
+def test_small_decoder_instance():
+    """decoder.rs:771-799."""
+    H = np.array([[1, 1, 1, 1, 0, 0], [0, 0, 1, 1, 0, 1], [1, 0, 0, 1, 1, 0]], dtype=np.int8)
+    dec = qary.decoder_class("DecoderN6R3V3C4B7")(H, 10)
+    with np.errstate(divide="ignore"):
+        assert dec.min_sum(one_bad_symbol(6, 15, 7)) == [0] * 6
+
+
+def test_medium_decoder_instance(golden):
+    """decoder.rs:819-854 (benches/parity_check_150_450.txt)."""
+    H = S.TannerGraph.from_coo(golden["parity_check_150_450"]).to_dense(np.int8)
+    dec = qary.decoder_class("DecoderN450R150V3C7B7")(H, 10)
+    assert dec.min_sum(one_bad_symbol(450, 15, 7)) == [0] * 450
+
+
+def test_fer_doctest():
+    """simulate_frame_error_rate_rust doctest, decode.py:192-209: seed 1, 1 run -> 1."""
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "sca-ldpc_amd", "dropin"))
+    import simulate_rs
+
+    rng = S.codes.make_random_state(1)
+    g = S.codes.make_regular_ldpc_identity_graph(300, 150, 3, 6, rng)
+    H = g.to_dense(np.int8)
+    n, r = g.n, g.m
+    v, c = np.count_nonzero(H, axis=0).max(), np.count_nonzero(H, axis=1).max()
+    decoder = getattr(simulate_rs, f"DecoderN{n}R{r}V{v}C{c}B1")(H.astype(np.int8), 5)
+    p = 1 / 3
+    good, bad = np.array([p, 1.75 * p, 0.25 * p]), np.array([p, 0.25 * p, 1.75 * p])
+    succ = run = 0
+    while run < 1:
+        ch = np.zeros((n, 3), dtype=np.float32)
+        errs = 0
+        for i in range(n):
+            if rng.rand() < 0.005:
+                ch[i] = bad
+                errs += 1
+            else:
+                ch[i] = good
+        if not errs:
+            continue
+        succ += int(decoder.min_sum(ch.copy()) == [0] * n)
+        run += 1
+    assert succ == 1
+
+
+@pytest.mark.parametrize("batch", [1, 70, 300])
+def test_config4_vs_oracle(oracle, golden, batch):
+    """BASELINE config 4 shape: 150x450 regular+identity (seed 1), Q=3, 5 iterations; noisy pmfs."""
+    g = S.TannerGraph.from_coo(golden["generators"]["regular_identity_300_150_3_6_s1"])
+    rng = np.random.RandomState(40 + batch)
+    p = 1 / 3
+    good, bad = np.array([p, 1.75 * p, 0.25 * p]), np.array([p, 0.25 * p, 1.75 * p])
+    distr = np.array(golden["distr_files"]["qary_distr"])
+    pmf = np.zeros((batch, 450, 3), dtype=np.float32)
+    for b in range(batch):
+        if b % 3 == 2:  # qary_distr.txt rows cycled over positions (decode.py:88-91)
+            pmf[b] = distr[np.arange(450) % len(distr)]
+        else:
+            mask = rng.rand(450) < (0.005 if b % 3 == 0 else 0.08)
+            pmf[b] = np.where(mask[:, None], bad, good)
+    dec = qary.decoder_class("DecoderN450R150V3C7B1")(g.to_dense(np.int8), 5)
+    got = dec.min_sum_batch(pmf)
+    ref = oracle.qary_min_sum_batch(g, 3, pmf, 5, threads=8)
+    assert np.array_equal(got, ref)
+    if batch >= 70:
+        assert (got != 0).any() and (got == 0).all(axis=1).any()  # both outcomes exercised
+
+
+def test_signed_entries_and_inf_vs_oracle(oracle):
+    """H with -1 entries (index reversal, decoder.rs:164-172), Q=5, zero-probability symbols (+inf LLRs)."""
+    rng = np.random.RandomState(3)
+    R, N, B = 12, 30, 2
+    H = np.zeros((R, N), dtype=np.int8)
+    for r in range(R):
+        cols = rng.choice(N, 4, replace=False)
+        H[r, cols] = rng.choice([-1, 1], size=4)
+    g = S.TannerGraph.from_dense(H)
+    pmf = rng.dirichlet(np.ones(5), size=(40, N)).astype(np.float32)
+    pmf[:, ::7, 0] = 0.0
+    pmf /= pmf.sum(axis=2, keepdims=True)
+    name = f"DecoderN{N}R{R}V{int(g.col_degrees().max())}C{int(g.row_degrees().max())}B{B}"
+    dec = qary.decoder_class(name)(H, 6)
+    with np.errstate(divide="ignore"):
+        got = dec.min_sum_batch(pmf)
+        ref = oracle.qary_min_sum_batch(g, 5, pmf, 6, threads=8)
+    assert np.array_equal(got, ref)
+
+
+def test_special_decoder_vs_oracle(oracle, golden):
+    """DecoderSpecial on a Kyber-shaped H = [H' | I] (scaled down: SW = 3 so the brute-force
+    enumeration is 125 assignments per check); the reference has no live test for this path
+    (decoder_special.rs:691-746 are commented out) -> parity against the restatement only."""
+    rng = S.codes.make_random_state(0)
+    g = S.codes.make_qary_qc_graph(16, 3, 3, rng, 2)  # 32 x 80, row weight 4, entries +-1
+    H = g.to_dense(np.int8)
+    R, N, B, BSUM = 32, 80, 2, 6
+    r2 = np.random.RandomState(9)
+    pb = r2.dirichlet(np.ones(5) * 0.6, size=(50, N - R)).astype(np.float32)
+    ps = r2.dirichlet(np.ones(13) * 0.6, size=(50, R)).astype(np.float32)
+    dec = qary.decoder_class("DecoderN80R32SW3")(H, 4)
+    got = dec.min_sum_batch(pb, ps)
+    ref = oracle.qary_special_batch(g, B, BSUM, pb, ps, 4, threads=8)
+    assert np.array_equal(got, ref)
+    assert dec.min_sum(pb[0], ps[0]) == [int(x) for x in ref[0]]
+
+
+def test_kyber_shape_sample(oracle, golden):
+    """DecoderN1280R512SW6 (the decoder 'used in the paper', kyber.py:381-382): 5^6 assignments per
+    check; 3 codewords against the oracle."""
+    g = S.TannerGraph.from_coo(golden["generators"]["qary_qc_256_6_3_s0_cb2"])
+    H = g.to_dense(np.int8)
+    r2 = np.random.RandomState(10)
+    pb = r2.dirichlet(np.ones(5), size=(3, 768)).astype(np.float32)
+    ps = r2.dirichlet(np.ones(25), size=(3, 512)).astype(np.float32)
+    dec = qary.decoder_class("DecoderN1280R512SW6")(H, 2)
+    got = dec.min_sum_batch(pb, ps)
+    ref = oracle.qary_special_batch(g, 2, 12, pb, ps, 2, threads=8)
+    assert np.array_equal(got, ref)
+
+
+def test_errors():
+    H = np.array([[1, 1, 0], [0, 1, 1]], dtype=np.int8)
+    cls = qary.decoder_class("DecoderN3R2V2C2B1")
+    dec = cls(H, 2)
+    with pytest.raises(Exception, match="sum"):
+        dec.min_sum(np.full((3, 3), 0.5, dtype=np.float32))
+    with pytest.raises(ValueError):
+        dec.min_sum(np.zeros((4, 3), dtype=np.float32))
+    with pytest.raises(ValueError):
+        cls(np.ones((2, 3), dtype=np.int8), 2)  # degree overflow
+    with pytest.raises(TypeError):
+        cls(H.astype(np.int64), 2)
+    with pytest.raises(AttributeError):
+        qary.decoder_class("NotADecoder")
