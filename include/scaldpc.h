@@ -94,10 +94,11 @@ int scaldpc_bp_decode_batch(scaldpc_bp *h, const uint8_t *in, int32_t input_kind
                             void *stream, uint8_t *out_bits, float *out_llr, int32_t *out_iters,
                             uint8_t *out_conv);
 /*
- * Measurement aid for bench.py: run `iters` iterations of `method` on the state
- * left by the last decode (same batch), bracketing every kernel launch with HIP
- * events on the launch stream.  ms[0] = total check-kernel ms, ms[1] = total
- * variable-kernel ms, launches[0..1] = number of launches of each.
+ * Measurement aid for bench.py: on the message state left by the last decode, run
+ * `iters` back-to-back launches of the check kernel and then of the variable kernel
+ * of `method` over one tile group, each series bracketed by HIP events on the launch
+ * stream.  ms[0] / ms[1] = total ms of each series, launches[0..1] = launches in it,
+ * launches[2] = codewords swept per launch.  (ms: float[2], launches: int32[3].)
  */
 int scaldpc_bp_time_kernels(scaldpc_bp *h, int32_t iters, int32_t method, float alpha, void *stream,
                             float *ms, int32_t *launches);

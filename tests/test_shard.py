@@ -1,0 +1,78 @@
+"""The N>1 path: trials sharded over ranks by global index, one gather at the end.
+world_size-2 `gloo` run on CPU (decoders injected from the oracle) must reproduce the
+single-process result trial for trial."""
+import importlib
+import os
+import socket
+
+import numpy as np
+import pytest
+
+from helpers import S
+
+shard = importlib.import_module("sca-ldpc_amd.shard")
+trials = importlib.import_module("sca-ldpc_amd.trials")
+
+
+def test_trial_range_partitions():
+    for total in (0, 1, 7, 64, 1000):
+        for world in (1, 2, 3, 8):
+            spans = [shard.trial_range(total, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == total
+            assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
+            sizes = [b - a for a, b in spans]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def _instance():
+    N, W, R, omega, eps = 211, 5, 90, 3, 0.02
+    rng = np.random.RandomState(3)
+    sup = S.codes.make_random_ldpc_first_row(N, W, rng)
+    Hin = S.codes.hqc_check_graph(sup, N, rng.permutation(N)[:R])
+    return N, omega, eps, Hin
+
+
+def _decode_range(start, stop):
+    from oracle import pyoracle
+
+    N, omega, eps, Hin = _instance()
+    msg, ys = trials.hqc_trials(Hin, omega, eps, stop - start, base_seed=2, first_index=start)
+    r = pyoracle.bp_decode_batch(Hin.with_identity(), trials.hqc_priors(N, Hin.m, omega, eps), msg, 1, 20, "min_sum",
+                                 dtype="f32", threads=2)
+    return trials.success(r["bits"], ys, N).astype(np.uint8)
+
+
+def _worker(rank, world, port, total, q):
+    import torch.distributed as dist
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    a, b = shard.trial_range(total, rank, world)
+    full = shard.gather_results(_decode_range(a, b), total, rank, world)
+    if rank == 0:
+        q.put(full)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_gloo_matches_single_process():
+    import torch.multiprocessing as mp
+
+    total = 37  # ragged: 19 + 18
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, total, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    full = q.get(timeout=240)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    single = _decode_range(0, total)
+    assert np.array_equal(full, single)
+    assert 0 < single.sum() < total  # both outcomes present
