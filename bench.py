@@ -160,6 +160,7 @@ def main():
             "converged_rate": conv,
             "kernel_ms": {"check_per_launch": ms_check, "var_pass": ms_var_pass},
         }
+        traffic = pmc_traffic(args.workload, batch, swept, "k_check_minsum<false>" if dominant_is_check else "k_check_tanh")
         if dominant_is_check:
             out["roofline"] = {
                 "bound": "hbm",
@@ -168,7 +169,7 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": check_gbs / HBM_PEAK_GBS,
-                "traffic": None,
+                "traffic": traffic,
             }
         else:
             pass_gbs = check_gbs
@@ -187,6 +188,21 @@ def main():
     dec.close()
     if world > 1:
         dist.destroy_process_group()
+
+
+def pmc_traffic(workload, batch, swept, kernel):
+    """Bytes per launch of the dominant kernel from rocprofv3 PMC passes (FETCH_SIZE x2,
+    WRITE_SIZE x1 -- the gfx950 corrections of MI355X_MICROARCH.md, re-verified on
+    profiles/microbench), recorded under profiles/ for exactly this workload geometry.
+    Counters cannot be read from inside the process, so this is the committed measurement,
+    or None when the run's geometry differs from the profiled one."""
+    try:
+        d = json.load(open(os.path.join(ROOT, "profiles", f"r01_pmc_traffic_{workload}.json")))
+        if d["batch"] == batch and d["tile_group_codewords"] == swept:
+            return d["kernels"][kernel]["traffic_bytes"]
+    except Exception:
+        pass
+    return None
 
 
 def cpu_baseline(H, probs, msg, iters, method, E, budget_s):
