@@ -15,6 +15,10 @@
  *   scaldpc_bp_decode_batch      ldpc.bp_decoder.decode(v), simulate/decode.py:171, simulate/hqc.py:708
  *                                (batched: one call = `batch` independent decode() calls)
  *   scaldpc_bp_destroy           object lifetime
+ *   scaldpc_mc_fer_run           the per-trial body of simulate_frame_error_rate,
+ *                                simulate/decode.py:36-40,165-175 (noise, syndrome, decode, compare)
+ *   scaldpc_mc_hqc_run           hqc.decode() input assembly + success test for synthetic trials,
+ *                                simulate/hqc.py:684-705,742-749
  *   scaldpc_qary_create          simulate_rs Decoder::new via PyO3 `#[new]`,
  *                                simulate_rs/src/pydecoder.rs:24-45 -> simulate_rs/src/decoder.rs:494-553
  *   scaldpc_qary_min_sum_batch   PyO3 `min_sum`, simulate_rs/src/pydecoder.rs:53-65
@@ -106,6 +110,33 @@ int scaldpc_bp_time_kernels(scaldpc_bp *h, int32_t iters, int32_t method, float 
  * (largest group whose in-place message array stays within ~200 MB of Infinity Cache). */
 int scaldpc_bp_set_tile_group(scaldpc_bp *h, int32_t tiles);
 void scaldpc_bp_destroy(scaldpc_bp *h);
+
+/* ------------------------------------------- Monte-Carlo helpers on the device (K6) */
+/*
+ * The per-trial helpers of the reference's drivers -- draw the noise, form the syndrome,
+ * decode, compare -- without a host round trip per trial.  Random numbers: Philox4x32-10,
+ * key = seed, counter = (block, stream, GLOBAL trial index): a trial's inputs depend only
+ * on (seed, first_trial + i), not on batch size or GPU count.
+ *
+ * scaldpc_mc_fer_run  = the body of simulate_frame_error_rate (simulate/decode.py:165-175):
+ *   error_i ~ Bernoulli(channel_probs[i]) (flip iff stream-0 word i < floor(p_i 2^32)),
+ *   syndrome = H error, decode, success = (decoding == error everywhere).
+ *   out_error (optional) uint8 [batch][n]: the sampled error vectors.
+ * scaldpc_mc_hqc_run  = synthetic hqc.decode() trials (simulate/hqc.py:684-705,742-749) on
+ *   H = [Hin | I_R]: y = omega distinct positions in [0, N) (stream-1 candidates
+ *   mulhi(word, N), duplicates skipped), checks = Hin y with each bit flipped with
+ *   probability eps (stream 0), msg = [0]*N ++ checks, decode in received-vector mode,
+ *   success = (decoded[:N] == indicator(y)).
+ *   out_msg (optional) uint8 [batch][n]; out_y (optional) int32 [batch][omega], in draw order.
+ * out_success uint8 [batch] required; out_iters int32 [batch] optional.
+ * flags: SCALDPC_F_EARLY_EXIT, SCALDPC_F_DEVICE_IO (outputs are device pointers).
+ */
+int scaldpc_mc_fer_run(scaldpc_bp *h, int64_t first_trial, int32_t batch, uint64_t seed, int32_t max_iter,
+                       int32_t method, float alpha, uint32_t flags, void *stream, uint8_t *out_success,
+                       int32_t *out_iters, uint8_t *out_error);
+int scaldpc_mc_hqc_run(scaldpc_bp *h, int32_t omega, double eps, int64_t first_trial, int32_t batch, uint64_t seed,
+                       int32_t max_iter, int32_t method, float alpha, uint32_t flags, void *stream,
+                       uint8_t *out_success, int32_t *out_iters, uint8_t *out_msg, int32_t *out_y);
 
 /* ------------------------------------------------------------ q-ary min-sum */
 typedef struct scaldpc_qary scaldpc_qary;

@@ -25,7 +25,7 @@ QERR = {
 
 def build(force=False):
     so = os.path.join(_HERE, "liboracle.so")
-    srcs = [os.path.join(_HERE, f) for f in ("bp_oracle.c", "bp_oracle_impl.h", "qary_oracle.c")]
+    srcs = [os.path.join(_HERE, f) for f in ("bp_oracle.c", "bp_oracle_impl.h", "qary_oracle.c", "mc_oracle.c")]
     if force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
         subprocess.check_call(["make", "-C", _HERE, "liboracle.so"], stdout=subprocess.DEVNULL)
     return so
@@ -130,3 +130,25 @@ def qary_special_batch(g, B, BSUM, pmf_b, pmf_s, max_iter, threads=1):
     if rc:
         raise RuntimeError(QERR.get(rc, str(rc)))
     return out[0] if single else out
+
+
+def philox4x32_10(ctr, key):
+    c = (C.c_uint32 * 4)(*ctr)
+    k = (C.c_uint32 * 2)(*key)
+    o = (C.c_uint32 * 4)()
+    lib().oracle_philox4x32_10(c, k, o)
+    return [int(x) for x in o]
+
+
+def mc_bernoulli(seed, first, batch, length, probs=None, p0=0.0):
+    out = np.zeros((batch, length), dtype=np.uint8)
+    pr = None if probs is None else np.ascontiguousarray(probs, dtype=np.float64)
+    lib().oracle_mc_bernoulli(C.c_uint64(seed), C.c_int64(first), C.c_int(batch), C.c_int(length),
+                              None if pr is None else _p(pr, C.c_double), C.c_double(p0), _p(out, C.c_uint8))
+    return out
+
+
+def mc_hqc_secret(seed, first, batch, N, omega):
+    y = np.zeros((batch, omega), dtype=np.int32)
+    lib().oracle_mc_hqc_secret(C.c_uint64(seed), C.c_int64(first), C.c_int(batch), C.c_int(N), C.c_int(omega), _p(y, C.c_int32))
+    return y

@@ -50,9 +50,17 @@ def _declare(lib):
     lib.scaldpc_bp_set_tile_group.argtypes = [vp, C.c_int32]
     lib.scaldpc_bp_destroy.argtypes = [vp]
     lib.scaldpc_bp_destroy.restype = None
+    lib.scaldpc_mc_fer_run.argtypes = [
+        vp, C.c_int64, C.c_int32, C.c_uint64, C.c_int32, C.c_int32, C.c_float, C.c_uint32, vp, vp, vp, vp,
+    ]  # fmt: skip
+    lib.scaldpc_mc_hqc_run.argtypes = [
+        vp, C.c_int32, C.c_double, C.c_int64, C.c_int32, C.c_uint64, C.c_int32, C.c_int32, C.c_float, C.c_uint32,
+        vp, vp, vp, vp, vp,
+    ]  # fmt: skip
     for name in (
         "scaldpc_device_count", "scaldpc_set_device", "scaldpc_bp_create", "scaldpc_bp_set_channel_probs",
-        "scaldpc_bp_decode_batch", "scaldpc_bp_time_kernels", "scaldpc_bp_set_tile_group",
+        "scaldpc_bp_decode_batch", "scaldpc_bp_time_kernels", "scaldpc_bp_set_tile_group", "scaldpc_mc_fer_run",
+        "scaldpc_mc_hqc_run",
     ):  # fmt: skip
         getattr(lib, name).restype = C.c_int
     lib.scaldpc_qary_create.argtypes = [C.c_int32, C.c_int32, C.c_int32, vp, C.c_int32, p(vp)]

@@ -198,6 +198,40 @@ class BpDecoder:
         )
         return {"ms_check": ms[0], "ms_var": ms[1], "launches_check": ln[0], "launches_var": ln[1], "codewords": ln[2]}
 
+    # -- Monte-Carlo helpers on the device (K6) --------------------------------------
+    def mc_fer_run(self, runs, seed, first_trial=0, max_iter=None, early_exit=True, want_errors=False):
+        """`runs` trials of the FER loop body (simulate/decode.py:165-175) entirely on the
+        device: error ~ Bernoulli(channel_probs), syndrome, decode, compare.
+        Returns dict(success uint8 [runs], iters int32 [runs], errors uint8 [runs, n] or None)."""
+        succ = np.empty(runs, dtype=np.uint8)
+        iters = np.empty(runs, dtype=np.int32)
+        err = np.empty((runs, self.n), dtype=np.uint8) if want_errors else None
+        _lib.check(
+            self._lib.scaldpc_mc_fer_run(
+                self._h, int(first_trial), int(runs), int(seed), self.max_iter if max_iter is None else int(max_iter),
+                self._method, self.ms_scaling_factor, _lib.F_EARLY_EXIT if early_exit else 0, None, _lib.ptr(succ),
+                _lib.ptr(iters), _lib.ptr(err),
+            )  # fmt: skip
+        )
+        return {"success": succ, "iters": iters, "errors": err}
+
+    def mc_hqc_run(self, runs, omega, eps, seed, first_trial=0, max_iter=None, early_exit=True, want_inputs=False):
+        """`runs` synthetic hqc.decode() trials (simulate/hqc.py:684-705,742-749) on H = [Hin | I]:
+        secret y, noisy checks, msg = [0]*N ++ checks, decode, success = (decoded[:N] == y).
+        Returns dict(success, iters, msg uint8 [runs, n] or None, y int32 [runs, omega] or None)."""
+        succ = np.empty(runs, dtype=np.uint8)
+        iters = np.empty(runs, dtype=np.int32)
+        msg = np.empty((runs, self.n), dtype=np.uint8) if want_inputs else None
+        y = np.empty((runs, omega), dtype=np.int32) if want_inputs else None
+        _lib.check(
+            self._lib.scaldpc_mc_hqc_run(
+                self._h, int(omega), float(eps), int(first_trial), int(runs), int(seed),
+                self.max_iter if max_iter is None else int(max_iter), self._method, self.ms_scaling_factor,
+                _lib.F_EARLY_EXIT if early_exit else 0, None, _lib.ptr(succ), _lib.ptr(iters), _lib.ptr(msg), _lib.ptr(y),
+            )  # fmt: skip
+        )
+        return {"success": succ, "iters": iters, "msg": msg, "y": y}
+
     def set_tile_group(self, tiles):
         _lib.check(self._lib.scaldpc_bp_set_tile_group(self._h, int(tiles)))
 

@@ -504,6 +504,122 @@ __global__ __launch_bounds__(256) void k_var(Buckets bk, const int *__restrict__
     }
 }
 
+// ---------------------------------------------------------------------------
+// K6  Monte-Carlo helpers: per-trial noise sampling, syndrome and success compare on the
+// device (the reference does these per position in Python: simulate/decode.py:36-40,
+// 166-168, 173-175; simulate/hqc.py:684-705, 742-749).
+// Random numbers: Philox4x32-10 (Salmon et al., SC'11), counter-based, keyed by the seed;
+// counter = (block, stream, trial_lo, trial_hi) with the GLOBAL trial index, so a trial's
+// inputs do not depend on batch size, tile position or the number of GPUs.
+//   stream 0 word x : Bernoulli(p_x) for position x      (flip iff word < floor(p_x * 2^32))
+//   stream 1 word j : j-th candidate position of the HQC secret, pos = mulhi(word, N),
+//                     accepted if not chosen before, until omega are accepted
+// ---------------------------------------------------------------------------
+struct U4 { unsigned x, y, z, w; };
+
+__device__ __forceinline__ U4 philox4x32_10(U4 c, unsigned k0, unsigned k1)
+{
+#pragma unroll
+    for (int r = 0; r < 10; r++) {
+        const unsigned hi0 = __umulhi(0xD2511F53u, c.x), lo0 = 0xD2511F53u * c.x;
+        const unsigned hi1 = __umulhi(0xCD9E8D57u, c.z), lo1 = 0xCD9E8D57u * c.z;
+        c = U4{hi1 ^ c.y ^ k0, lo1, hi0 ^ c.w ^ k1, lo0};
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    return c;
+}
+
+// planes[t][x] (bit c) = [stream-`stream` word x of trial first + 64 t + c  <  thr_x]; XOR_INTO flips
+// an existing plane instead.  wave = (tile, 16 consecutive x).  grid (ceil(len/64), T), block 256.
+template <bool XOR_INTO>
+__global__ __launch_bounds__(256) void k_mc_bernoulli(u64 *__restrict__ planes, int len, int batch, long first,
+                                                      unsigned stream, unsigned k0, unsigned k1,
+                                                      const u64 *__restrict__ thr, u64 thr0)
+{
+    const int lane = threadIdx.x & 63;
+    const int x0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 16;
+    const int t = blockIdx.y;
+    if (x0 >= len) return;
+    const long b = (long)t * TW + lane;
+    const u64 trial = (u64)(first + b);
+    for (int q = 0; q < 4; q++) {
+        const int xb = x0 + 4 * q;
+        if (xb >= len) break;
+        const U4 r = philox4x32_10(U4{(unsigned)(xb >> 2), stream, (unsigned)trial, (unsigned)(trial >> 32)}, k0, k1);
+        const unsigned w[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int x = xb + j;
+            if (x < len) {
+                const u64 th = thr ? thr[x] : thr0;
+                const u64 m = __ballot(b < batch && (u64)w[j] < th);
+                if (lane == 0) {
+                    if (XOR_INTO)
+                        planes[(size_t)t * len + x] ^= m;
+                    else
+                        planes[(size_t)t * len + x] = m;
+                }
+            }
+        }
+    }
+}
+
+// HQC secret: omega distinct positions per trial, set as bits of planes[t][pos] (pos < N; the
+// plane rows have stride n).  One wave per tile, lane = trial; chosen positions kept in LDS.
+// grid T, block 64, dynamic LDS omega*64*4 B.
+__global__ __launch_bounds__(64) void k_mc_hqc_secret(u64 *__restrict__ planes, int n, int N, int omega, int batch,
+                                                      long first, unsigned k0, unsigned k1, int *__restrict__ out_y)
+{
+    extern __shared__ int chosen[];  // [omega][64]
+    const int lane = threadIdx.x, t = blockIdx.x;
+    const long b = (long)t * TW + lane;
+    if (b >= batch) return;
+    const u64 trial = (u64)(first + b);
+    unsigned j = 0;
+    U4 r{};
+    for (int i = 0; i < omega; i++) {
+        for (;;) {
+            if ((j & 3) == 0) r = philox4x32_10(U4{j >> 2, 1u, (unsigned)trial, (unsigned)(trial >> 32)}, k0, k1);
+            const unsigned w = (j & 3) == 0 ? r.x : (j & 3) == 1 ? r.y : (j & 3) == 2 ? r.z : r.w;
+            j++;
+            const int pos = (int)__umulhi(w, (unsigned)N);
+            bool dup = false;
+            for (int q = 0; q < i; q++) dup |= chosen[q * 64 + lane] == pos;
+            if (!dup) {
+                chosen[i * 64 + lane] = pos;
+                atomicOr(planes + (size_t)t * n + pos, 1ull << lane);
+                if (out_y) out_y[(size_t)b * omega + i] = pos;
+                break;
+            }
+        }
+    }
+}
+
+// diff[t] |= OR_v (a[t][v] ^ b[t][v]) over v < nv (plane rows of stride n).  grid (ceil(nv/256), T).
+__global__ __launch_bounds__(256) void k_mc_compare(const u64 *__restrict__ a, const u64 *__restrict__ bq, int n, int nv,
+                                                    u64 *__restrict__ diff)
+{
+    const int v = blockIdx.x * 256 + threadIdx.x;
+    const int t = blockIdx.y;
+    u64 d = 0;
+    if (v < nv) d = a[(size_t)t * n + v] ^ bq[(size_t)t * n + v];
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) d |= __shfl_xor(d, off);
+    if ((threadIdx.x & 63) == 0 && d) atomicOr(diff + t, d);
+}
+
+// success[b] = !diff bit; iters passthrough.  grid T, block 64.
+__global__ __launch_bounds__(64) void k_mc_result(const u64 *__restrict__ diff, const int *__restrict__ iters, int batch,
+                                                  uint8_t *__restrict__ out_success, int *__restrict__ out_iters)
+{
+    const int t = blockIdx.x, c = threadIdx.x;
+    const long b = (long)t * TW + c;
+    if (b >= batch) return;
+    out_success[b] = (uint8_t)(((diff[t] >> c) & 1) ^ 1);
+    if (out_iters) out_iters[b] = iters[b];
+}
+
 struct HostBuckets {
     Buckets bk;
     std::vector<int> list;
@@ -541,6 +657,14 @@ struct scaldpc_bp {
     int *d_out_iters = nullptr;
     size_t cap_in = 0, cap_out_bits = 0, cap_out_llr = 0, cap_out_b = 0;
     int *h_remaining = nullptr;  // pinned
+    // Monte-Carlo helpers
+    std::vector<double> h_probs;
+    u64 *d_thr = nullptr, *d_mc = nullptr, *d_diff = nullptr;
+    int *d_ylist = nullptr;
+    uint8_t *d_succ = nullptr;
+    size_t cap_mc = 0, cap_ylist = 0, cap_succ = 0, cap_diff = 0;
+    bool thr_valid = false;
+    int identity_from = -1;  // n - m if the last m columns of H are I_m (H = [Hin | I]), else -1
     hipStream_t own_stream = nullptr;
     int last_group = 0;  // tiles of the last decoded group (for scaldpc_bp_time_kernels)
     std::mutex mu;
@@ -690,6 +814,60 @@ float alpha_for(float alpha, int it)
     return alpha == 0.0f ? (float)(1.0 - std::pow(2.0, -1.0 * it)) : alpha;
 }
 
+// The decode proper, on inputs already staged as planes (h->d_synd; h->d_recv when the
+// caller wants e XOR v): state reset, then all iterations of one cache-resident tile
+// group after the other.  Results stay on the device (h->d_hard / d_post / d_conv / d_iters).
+int run_core(scaldpc_bp *h, int batch, int T, int G, int max_iter, int method, float alpha, bool early,
+             bool want_post, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_init_state, dim3(T), dim3(64), 0, s, batch, max_iter, h->d_done, h->d_conv, h->d_unsat,
+                       h->d_iters);
+    LAUNCH_CHECK();
+    SC_HIP(hipMemsetAsync(h->d_hard, 0, sizeof(u64) * (size_t)T * h->n, s));
+
+    // ---- iterate, one cache-resident tile group at a time ----------------------
+    const int poll_every = 4;
+    const int skip = early ? 1 : 0;
+    for (int g0 = 0; g0 < T; g0 += G) {
+        const int g = std::min(G, T - g0);
+        const u64 *synd_g = h->d_synd + (size_t)g0 * h->m;
+        u64 *hard_g = h->d_hard + (size_t)g0 * h->n;
+        u64 *done_g = h->d_done + g0;
+        u64 *conv_g = h->d_conv + g0;
+        u64 *unsat_g = h->d_unsat + g0;
+        int *iters_g = h->d_iters + (size_t)g0 * TW;
+        float *post_g = want_post ? h->d_post + (size_t)g0 * h->n * TW : nullptr;
+        if (h->E) {
+            hipLaunchKernelGGL(k_init_msg, dim3((unsigned)((h->E + 3) / 4), g), dim3(256), 0, s, h->d_col_idx,
+                               h->d_prior, h->d_msg, h->E);
+            LAUNCH_CHECK();
+        }
+        if (early) SC_HIP(hipMemsetAsync(h->d_remaining, 0, sizeof(int) * ((size_t)max_iter + 2), s));
+        for (int it = 1; it <= max_iter; it++) {
+            const bool last = it == max_iter;
+            SC_TRY(launch_check(h, method, alpha_for(alpha, it), g, synd_g, done_g, skip, s));
+            SC_TRY(launch_var(h, g, post_g, hard_g, done_g, skip, (early || last) ? 1 : 0, s));
+            if (early || last) {
+                hipLaunchKernelGGL(k_parity<true>, dim3((h->m + 255) / 256, g), dim3(256), 0, s, h->d_row_ptr,
+                                   h->d_col_idx, hard_g, h->m, h->n, const_cast<u64 *>(synd_g), unsat_g,
+                                   (const u64 *)done_g);
+                LAUNCH_CHECK();
+                hipLaunchKernelGGL(k_finalize, dim3(g), dim3(64), 0, s, it, early ? 1 : 0, done_g, conv_g, unsat_g,
+                                   iters_g, h->d_remaining + it);
+                LAUNCH_CHECK();
+            }
+            if (early && !last && (it % poll_every == 0 || it == 1)) {
+                SC_HIP(hipMemcpyAsync(h->h_remaining + it, h->d_remaining + it, sizeof(int), hipMemcpyDeviceToHost, s));
+                SC_HIP(hipStreamSynchronize(s));
+                if (h->h_remaining[it] == 0) break;
+            }
+        }
+    }
+    h->last_group = std::min(G, T);
+
+    return 0;
+}
+
 }  // namespace
 
 // ===========================================================================
@@ -758,6 +936,14 @@ int scaldpc_bp_create(int32_t m, int32_t n, int64_t nnz, const int32_t *row_ptr,
     h->var_bk = hv.bk;
     h->row_bk = hr.bk;
     h->need_scratch = hv.has_generic || hr.has_generic;
+    if (n > m) {  // H = [Hin | I_m]?  (what hqc.decode builds, hqc.py:680)
+        bool ident = true;
+        for (int r = 0; r < m && ident; r++) {
+            const int j = n - m + r;
+            ident = cdeg[j] == 1 && row_ptr[r + 1] > row_ptr[r] && col_idx[row_ptr[r + 1] - 1] == j;
+        }
+        h->identity_from = ident ? n - m : -1;
+    }
 
     int rc = 0;
     auto up = [&](int **d, const int *src, size_t cnt) -> int {
@@ -795,6 +981,8 @@ int scaldpc_bp_set_channel_probs(scaldpc_bp *h, const double *probs)
         llr[j] = logf((1.0f - p) / p);
     }
     SC_HIP(hipMemcpy(h->d_prior, llr.data(), sizeof(float) * h->n, hipMemcpyHostToDevice));
+    h->h_probs.assign(probs, probs + h->n);
+    h->thr_valid = false;
     h->have_prior = true;
     return 0;
 }
@@ -850,50 +1038,7 @@ int scaldpc_bp_decode_batch(scaldpc_bp *h, const uint8_t *in, int32_t input_kind
                            h->d_recv, h->m, h->n, h->d_synd, (u64 *)nullptr, (const u64 *)nullptr);
         LAUNCH_CHECK();
     }
-    hipLaunchKernelGGL(k_init_state, dim3(T), dim3(64), 0, s, batch, max_iter, h->d_done, h->d_conv, h->d_unsat,
-                       h->d_iters);
-    LAUNCH_CHECK();
-    SC_HIP(hipMemsetAsync(h->d_hard, 0, sizeof(u64) * (size_t)T * h->n, s));
-
-    // ---- iterate, one cache-resident tile group at a time ----------------------
-    const int poll_every = 4;
-    const int skip = early ? 1 : 0;
-    for (int g0 = 0; g0 < T; g0 += G) {
-        const int g = std::min(G, T - g0);
-        const u64 *synd_g = h->d_synd + (size_t)g0 * h->m;
-        u64 *hard_g = h->d_hard + (size_t)g0 * h->n;
-        u64 *done_g = h->d_done + g0;
-        u64 *conv_g = h->d_conv + g0;
-        u64 *unsat_g = h->d_unsat + g0;
-        int *iters_g = h->d_iters + (size_t)g0 * TW;
-        float *post_g = out_llr ? h->d_post + (size_t)g0 * h->n * TW : nullptr;
-        if (h->E) {
-            hipLaunchKernelGGL(k_init_msg, dim3((unsigned)((h->E + 3) / 4), g), dim3(256), 0, s, h->d_col_idx,
-                               h->d_prior, h->d_msg, h->E);
-            LAUNCH_CHECK();
-        }
-        if (early) SC_HIP(hipMemsetAsync(h->d_remaining, 0, sizeof(int) * ((size_t)max_iter + 2), s));
-        for (int it = 1; it <= max_iter; it++) {
-            const bool last = it == max_iter;
-            SC_TRY(launch_check(h, method, alpha_for(alpha, it), g, synd_g, done_g, skip, s));
-            SC_TRY(launch_var(h, g, post_g, hard_g, done_g, skip, (early || last) ? 1 : 0, s));
-            if (early || last) {
-                hipLaunchKernelGGL(k_parity<true>, dim3((h->m + 255) / 256, g), dim3(256), 0, s, h->d_row_ptr,
-                                   h->d_col_idx, hard_g, h->m, h->n, const_cast<u64 *>(synd_g), unsat_g,
-                                   (const u64 *)done_g);
-                LAUNCH_CHECK();
-                hipLaunchKernelGGL(k_finalize, dim3(g), dim3(64), 0, s, it, early ? 1 : 0, done_g, conv_g, unsat_g,
-                                   iters_g, h->d_remaining + it);
-                LAUNCH_CHECK();
-            }
-            if (early && !last && (it % poll_every == 0 || it == 1)) {
-                SC_HIP(hipMemcpyAsync(h->h_remaining + it, h->d_remaining + it, sizeof(int), hipMemcpyDeviceToHost, s));
-                SC_HIP(hipStreamSynchronize(s));
-                if (h->h_remaining[it] == 0) break;
-            }
-        }
-    }
-    h->last_group = std::min(G, T);
+    SC_TRY(run_core(h, batch, T, G, max_iter, method, alpha, early, out_llr != nullptr, s));
 
     // ---- outputs --------------------------------------------------------------
     uint8_t *dbits = out_bits;
@@ -939,6 +1084,168 @@ int scaldpc_bp_decode_batch(scaldpc_bp *h, const uint8_t *in, int32_t input_kind
     return 0;
 }
 
+// ---------------------------------------------------------------------------
+// Monte-Carlo entry points (K6)
+// ---------------------------------------------------------------------------
+namespace {
+
+u64 bernoulli_threshold(double p) { return p >= 1.0 ? (1ull << 32) : p <= 0.0 ? 0ull : (u64)(p * 4294967296.0); }
+
+int mc_common_args(scaldpc_bp *h, int32_t batch, int32_t method, float alpha, uint8_t *out_success)
+{
+    if (!h || !out_success) return fail(SCALDPC_EINVAL, "NULL argument");
+    if (batch <= 0) return fail(SCALDPC_EINVAL, "batch must be positive (got %d)", batch);
+    if (method != SCALDPC_BP_PRODUCT_SUM && method != SCALDPC_BP_MIN_SUM)
+        return fail(SCALDPC_EINVAL, "unknown bp method %d", method);
+    if (!(alpha >= 0.0f)) return fail(SCALDPC_EINVAL, "ms_scaling_factor must be >= 0");
+    return 0;
+}
+
+int mc_finish(scaldpc_bp *h, int batch, int T, int nv, bool dev_io, hipStream_t s, uint8_t *out_success,
+              int32_t *out_iters)
+{
+    SC_TRY(grow(&h->d_diff, &h->cap_diff, (size_t)T));
+    SC_HIP(hipMemsetAsync(h->d_diff, 0, sizeof(u64) * (size_t)T, s));
+    hipLaunchKernelGGL(k_mc_compare, dim3((nv + 255) / 256, T), dim3(256), 0, s, h->d_hard, h->d_mc, h->n, nv,
+                       h->d_diff);
+    LAUNCH_CHECK();
+    uint8_t *ds = out_success;
+    int *di = out_iters;
+    if (!dev_io) {
+        SC_TRY(grow(&h->d_succ, &h->cap_succ, (size_t)batch));
+        ds = h->d_succ;
+        if (out_iters) {
+            if ((size_t)batch > h->cap_out_b) {
+                dev_free(h->d_out_iters); dev_free(h->d_out_conv);
+                h->cap_out_b = 0;
+                SC_TRY(dev_alloc(&h->d_out_iters, (size_t)batch));
+                SC_TRY(dev_alloc(&h->d_out_conv, (size_t)batch));
+                h->cap_out_b = batch;
+            }
+            di = h->d_out_iters;
+        }
+    }
+    hipLaunchKernelGGL(k_mc_result, dim3(T), dim3(64), 0, s, h->d_diff, h->d_iters, batch, ds, di);
+    LAUNCH_CHECK();
+    if (!dev_io) {
+        SC_HIP(hipMemcpyAsync(out_success, ds, (size_t)batch, hipMemcpyDeviceToHost, s));
+        if (out_iters) SC_HIP(hipMemcpyAsync(out_iters, di, sizeof(int) * (size_t)batch, hipMemcpyDeviceToHost, s));
+    }
+    SC_HIP(hipStreamSynchronize(s));
+    return 0;
+}
+
+int mc_export_bits(scaldpc_bp *h, const u64 *planes, int batch, int T, bool dev_io, hipStream_t s, uint8_t *out)
+{
+    uint8_t *d = out;
+    if (!dev_io) {
+        SC_TRY(grow(&h->d_out_bits, &h->cap_out_bits, (size_t)batch * h->n));
+        d = h->d_out_bits;
+    }
+    hipLaunchKernelGGL(k_unpack_bits, dim3((h->n + 255) / 256, T), dim3(256), 0, s, planes, (const u64 *)nullptr, h->n,
+                       batch, d);
+    LAUNCH_CHECK();
+    if (!dev_io) {
+        SC_HIP(hipMemcpyAsync(out, d, (size_t)batch * h->n, hipMemcpyDeviceToHost, s));
+        SC_HIP(hipStreamSynchronize(s));  // d_out_bits is reused below
+    }
+    return 0;
+}
+
+}  // namespace
+
+int scaldpc_mc_fer_run(scaldpc_bp *h, int64_t first_trial, int32_t batch, uint64_t seed, int32_t max_iter,
+                       int32_t method, float alpha, uint32_t flags, void *stream, uint8_t *out_success,
+                       int32_t *out_iters, uint8_t *out_error)
+{
+    SC_TRY(mc_common_args(h, batch, method, alpha, out_success));
+    std::lock_guard<std::mutex> lk(h->mu);
+    if (!h->have_prior) return fail(SCALDPC_EINVAL, "channel probabilities not set");
+    if (max_iter <= 0) max_iter = h->n;
+    const bool dev_io = flags & SCALDPC_F_DEVICE_IO, early = flags & SCALDPC_F_EARLY_EXIT;
+    hipStream_t s = stream ? (hipStream_t)stream : h->own_stream;
+    const int T = (batch + TW - 1) / TW;
+    if (T > 65535) return fail(SCALDPC_EINVAL, "batch %d too large for one call", batch);
+    const int G = (h->tile_group > 0) ? std::min(h->tile_group, T) : auto_group(h, T);
+    SC_TRY(ensure_workspace(h, T, G, false, max_iter));
+    SC_TRY(grow(&h->d_mc, &h->cap_mc, (size_t)T * h->n));
+    if (!h->thr_valid) {
+        if (!h->d_thr) SC_TRY(dev_alloc(&h->d_thr, (size_t)h->n));
+        std::vector<u64> thr(h->n);
+        for (int j = 0; j < h->n; j++) thr[j] = bernoulli_threshold(h->h_probs[j]);
+        SC_HIP(hipMemcpy(h->d_thr, thr.data(), sizeof(u64) * h->n, hipMemcpyHostToDevice));
+        h->thr_valid = true;
+    }
+    const unsigned k0 = (unsigned)seed, k1 = (unsigned)(seed >> 32);
+    // error ~ Bernoulli(p_i) per position (decode.py:166-167), syndrome = H error (decode.py:168)
+    hipLaunchKernelGGL(k_mc_bernoulli<false>, dim3((h->n + 63) / 64, T), dim3(256), 0, s, h->d_mc, h->n, batch,
+                       (long)first_trial, 0u, k0, k1, (const u64 *)h->d_thr, 0ull);
+    LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_parity<false>, dim3((h->m + 255) / 256, T), dim3(256), 0, s, h->d_row_ptr, h->d_col_idx,
+                       h->d_mc, h->m, h->n, h->d_synd, (u64 *)nullptr, (const u64 *)nullptr);
+    LAUNCH_CHECK();
+    if (out_error) SC_TRY(mc_export_bits(h, h->d_mc, batch, T, dev_io, s, out_error));
+    SC_TRY(run_core(h, batch, T, G, max_iter, method, alpha, early, false, s));
+    // success iff decoding == error everywhere (decode.py:173-175)
+    return mc_finish(h, batch, T, h->n, dev_io, s, out_success, out_iters);
+}
+
+int scaldpc_mc_hqc_run(scaldpc_bp *h, int32_t omega, double eps, int64_t first_trial, int32_t batch, uint64_t seed,
+                       int32_t max_iter, int32_t method, float alpha, uint32_t flags, void *stream,
+                       uint8_t *out_success, int32_t *out_iters, uint8_t *out_msg, int32_t *out_y)
+{
+    SC_TRY(mc_common_args(h, batch, method, alpha, out_success));
+    std::lock_guard<std::mutex> lk(h->mu);
+    if (!h->have_prior) return fail(SCALDPC_EINVAL, "channel probabilities not set");
+    if (h->identity_from < 0) return fail(SCALDPC_EINVAL, "parity-check matrix is not of the form [Hin | I] (hqc.py:680)");
+    const int N = h->identity_from;
+    if (omega < 0 || omega > N) return fail(SCALDPC_EINVAL, "omega must be in [0, N]");
+    if (!(eps >= 0.0 && eps <= 1.0)) return fail(SCALDPC_EINVAL, "eps must be a probability");
+    if ((size_t)omega * 64 * 4 > 64 * 1024) return fail(SCALDPC_EDEGREE, "omega %d too large for the LDS-resident sampler", omega);
+    if (max_iter <= 0) max_iter = h->n;
+    const bool dev_io = flags & SCALDPC_F_DEVICE_IO, early = flags & SCALDPC_F_EARLY_EXIT;
+    hipStream_t s = stream ? (hipStream_t)stream : h->own_stream;
+    const int T = (batch + TW - 1) / TW;
+    if (T > 65535) return fail(SCALDPC_EINVAL, "batch %d too large for one call", batch);
+    const int G = (h->tile_group > 0) ? std::min(h->tile_group, T) : auto_group(h, T);
+    SC_TRY(ensure_workspace(h, T, G, false, max_iter));
+    SC_TRY(grow(&h->d_mc, &h->cap_mc, (size_t)T * h->n));
+    int *dy = nullptr;
+    if (out_y) {
+        dy = out_y;
+        if (!dev_io) {
+            SC_TRY(grow(&h->d_ylist, &h->cap_ylist, (size_t)batch * std::max(omega, 1)));
+            dy = h->d_ylist;
+        }
+    }
+    const unsigned k0 = (unsigned)seed, k1 = (unsigned)(seed >> 32);
+    // x = [y | 0]: omega distinct positions;  checks = Hin y = H x  (hqc.py:1253-1257)
+    SC_HIP(hipMemsetAsync(h->d_mc, 0, sizeof(u64) * (size_t)T * h->n, s));
+    if (omega) {
+        hipLaunchKernelGGL(k_mc_hqc_secret, dim3(T), dim3(64), (size_t)omega * 64 * sizeof(int), s, h->d_mc, h->n, N, omega,
+                           batch, (long)first_trial, k0, k1, dy);
+        LAUNCH_CHECK();
+    }
+    hipLaunchKernelGGL(k_parity<false>, dim3((h->m + 255) / 256, T), dim3(256), 0, s, h->d_row_ptr, h->d_col_idx,
+                       h->d_mc, h->m, h->n, h->d_synd, (u64 *)nullptr, (const u64 *)nullptr);
+    LAUNCH_CHECK();
+    // each oracle answer wrong with probability eps
+    hipLaunchKernelGGL(k_mc_bernoulli<true>, dim3((h->m + 63) / 64, T), dim3(256), 0, s, h->d_synd, h->m, batch,
+                       (long)first_trial, 0u, k0, k1, (const u64 *)nullptr, bernoulli_threshold(eps));
+    LAUNCH_CHECK();
+    // msg = [0]*N ++ checks (hqc.py:703-705); its syndrome under H = [Hin | I] is `checks` itself
+    SC_HIP(hipMemsetAsync(h->d_recv, 0, sizeof(u64) * (size_t)T * h->n, s));
+    SC_HIP(hipMemcpy2DAsync(h->d_recv + N, sizeof(u64) * h->n, h->d_synd, sizeof(u64) * h->m, sizeof(u64) * h->m, T,
+                            hipMemcpyDeviceToDevice, s));
+    if (out_msg) SC_TRY(mc_export_bits(h, h->d_recv, batch, T, dev_io, s, out_msg));
+    SC_TRY(run_core(h, batch, T, G, max_iter, method, alpha, early, false, s));
+    if (out_y && !dev_io) {
+        SC_HIP(hipMemcpyAsync(out_y, dy, sizeof(int) * (size_t)batch * omega, hipMemcpyDeviceToHost, s));
+    }
+    // decoded[:N] = e[:N] XOR msg[:N] = e[:N] must equal the indicator of y (hqc.py:742-749)
+    return mc_finish(h, batch, T, N, dev_io, s, out_success, out_iters);
+}
+
 int scaldpc_bp_time_kernels(scaldpc_bp *h, int32_t iters, int32_t method, float alpha, void *stream, float *ms,
                             int32_t *launches)
 {
@@ -981,6 +1288,7 @@ void scaldpc_bp_destroy(scaldpc_bp *h)
     dev_free(h->d_conv); dev_free(h->d_unsat); dev_free(h->d_iters); dev_free(h->d_remaining);
     dev_free(h->d_in); dev_free(h->d_out_bits); dev_free(h->d_out_conv); dev_free(h->d_out_llr);
     dev_free(h->d_out_iters);
+    dev_free(h->d_thr); dev_free(h->d_mc); dev_free(h->d_diff); dev_free(h->d_ylist); dev_free(h->d_succ);
     if (h->h_remaining) (void)hipHostFree(h->h_remaining);
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
     delete h;

@@ -1,0 +1,58 @@
+"""K6 on the device vs its oracle: generated trials bit-exact, success flags equal to decoding
+the exported inputs through decode_batch, independence from batch split / first_trial."""
+import importlib
+
+import numpy as np
+import pytest
+
+from helpers import S, hqc_instance
+
+pytestmark = pytest.mark.gpu
+bp = importlib.import_module("sca-ldpc_amd.bp")
+trials = importlib.import_module("sca-ldpc_amd.trials")
+
+
+@pytest.mark.parametrize("method", ["min_sum", "product_sum"])
+def test_fer_run(oracle, golden, method):
+    rng = S.codes.make_random_state(0)
+    g = S.codes.make_regular_ldpc_graph(300, 150, 3, 6, rng)
+    probs = np.array([golden["distr_files"]["binary_distr"][i % 4][0] for i in range(g.n)]) * 0.3
+    dec = bp.bp_decoder(g, max_iter=30, bp_method=method, channel_probs=probs)
+    r = dec.mc_fer_run(300, seed=11, first_trial=5, want_errors=True)
+    err = oracle.mc_bernoulli(11, 5, 300, g.n, probs)
+    assert np.array_equal(r["errors"], err)
+    d = dec.decode_batch(g.syndrome(err), early_exit=True)
+    assert np.array_equal(r["success"], (d["bits"] == err).all(axis=1).astype(np.uint8))
+    assert np.array_equal(r["iters"], d["iters"])
+    assert 0 < r["success"].sum() < 300
+    # global-index determinism: two half-batches == one batch
+    a = dec.mc_fer_run(100, seed=11, first_trial=5)
+    b = dec.mc_fer_run(200, seed=11, first_trial=105)
+    assert np.array_equal(np.concatenate([a["success"], b["success"]]), r["success"])
+
+
+@pytest.mark.parametrize("eps", [0.0, 0.04])
+def test_hqc_run(oracle, eps):
+    H, Hin, probs, _, _ = hqc_instance(499, 7, 260, 5, eps, 1, seed=11, flip=False)
+    with np.errstate(divide="ignore"):
+        dec = bp.bp_decoder(H, max_iter=40, bp_method="product_sum", channel_probs=probs)
+    runs = 200
+    r = dec.mc_hqc_run(runs, omega=5, eps=eps, seed=42, first_trial=1000, want_inputs=True)
+    y = oracle.mc_hqc_secret(42, 1000, runs, 499, 5)
+    assert np.array_equal(r["y"], y)
+    yv = np.zeros((runs, 499), dtype=np.uint8)
+    np.put_along_axis(yv, y.astype(np.int64), 1, axis=1)
+    checks = Hin.syndrome(yv) ^ oracle.mc_bernoulli(42, 1000, runs, Hin.m, None, eps)
+    msg = np.concatenate([np.zeros((runs, 499), dtype=np.uint8), checks], axis=1)
+    assert np.array_equal(r["msg"], msg)
+    d = dec.decode_batch(msg, early_exit=True)
+    assert np.array_equal(r["success"], trials.success(d["bits"], y, 499).astype(np.uint8))
+    assert np.array_equal(r["iters"], d["iters"])
+    assert r["success"].mean() > 0.3
+
+
+def test_hqc_run_needs_identity_block():
+    g = S.codes.rep_code_graph(9)
+    dec = bp.bp_decoder(g, error_rate=0.1)
+    with pytest.raises(ValueError, match="Hin"):
+        dec.mc_hqc_run(4, omega=2, eps=0.1, seed=1)
