@@ -36,6 +36,9 @@ WORKLOADS = {
     "hqc192_minsum": ("hqc192", "N35851_W50_s0", "min_sum", 50),
     "hqc256_tanh": ("hqc256", "N57637_W50_s0", "product_sum", 50),
     "hqc128_tanh": ("hqc128", "N17669_W50_s0", "product_sum", 50),
+    # BASELINE config 5: Monte-Carlo sweep, trials generated/decoded/compared on the device,
+    # product_sum, early exit, max_iter 100 (hqc.py:696); --trials = whole-job trial count
+    "hqc128_mc": ("hqc128", "N17669_W50_s0", "product_sum", 100),
 }
 
 
@@ -50,6 +53,7 @@ def main():
     ap.add_argument("--tile-group", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--trials", type=int, default=65536, help="hqc128_mc: total trials over all ranks")
     args = ap.parse_args()
 
     import torch
@@ -80,8 +84,11 @@ def main():
     R, E, n = Hin.m, H.nnz, H.n
     batch = args.batch
     probs = trials.hqc_priors(N, R, omega, args.eps)
-    msg, ys = trials.hqc_trials(Hin, omega, args.eps, batch, base_seed=2, first_index=rank * batch)
+    if args.workload != "hqc128_mc":
+        msg, ys = trials.hqc_trials(Hin, omega, args.eps, batch, base_seed=2, first_index=rank * batch)
 
+    if args.workload == "hqc128_mc":
+        return mc_sweep(args, S, bp, lib, trials, H, N, omega, R, E, probs, iters, method, rank, world, local, dist)
     dec = bp.bp_decoder(H, max_iter=iters, bp_method=method, channel_probs=probs)
     if args.tile_group:
         dec.set_tile_group(args.tile_group)
@@ -185,6 +192,56 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(H, probs, msg, iters, method, E, args.cpu_seconds)
         print(json.dumps(out), flush=True)
+    dec.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def mc_sweep(args, S, bp, lib, trials, H, N, omega, R, E, probs, iters, method, rank, world, local, dist):
+    """BASELINE config 5: `--trials` synthetic hqc.decode() trials sharded over the ranks by
+    GLOBAL trial index (results independent of the GPU count), generated, decoded (early
+    exit, max_iter 100) and compared on the device in sub-batches of `--batch`; one gather
+    of the per-trial success flags at the end.  A "step" is one sub-batch."""
+    import torch
+
+    shard = importlib.import_module("sca-ldpc_amd.shard")
+    dec = bp.bp_decoder(H, max_iter=iters, bp_method=method, channel_probs=probs)
+    a, b = shard.trial_range(args.trials, rank, world)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    succ, its = [], []
+    for s0 in range(a, b, args.batch):
+        r = dec.mc_hqc_run(min(args.batch, b - s0), omega, args.eps, seed=2, first_trial=s0, early_exit=True)
+        succ.append(r["success"])
+        its.append(r["iters"])
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    succ = np.concatenate(succ) if succ else np.zeros(0, np.uint8)
+    its = np.concatenate(its) if its else np.zeros(0, np.int32)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    all_succ = shard.gather_results(succ, args.trials, rank, world, device=dev)
+    all_its = shard.gather_results(its, args.trials, rank, world, device=dev)
+    if rank == 0:
+        updates = 2.0 * E * float(all_its.astype(np.int64).sum())
+        print(json.dumps({
+            "metric": "edge_message_updates_per_s", "value": updates / dt, "unit": "directed edge-message updates/s",
+            "n_gpus": world, "steps": int(np.ceil((b - a) / args.batch)), "warmup": 0,
+            "ms_per_step": dt / max(1, np.ceil((b - a) / args.batch)) * 1e3, "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"hqc128 Monte-Carlo sweep, {args.trials} trials, eps={args.eps}, {method}, early exit, "
+                                   f"max_iter {iters}, sub-batches of {args.batch}, device-side trial generation"},
+            "trials_per_s": args.trials / dt, "decode_success_rate": float(all_succ.mean()),
+            "mean_iterations": float(all_its.mean()), "wall_s": dt,
+            "success_checksum": int(np.flatnonzero(all_succ == 0)[:1000].sum()),
+        }), flush=True)
     dec.close()
     if world > 1:
         dist.destroy_process_group()

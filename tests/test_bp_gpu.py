@@ -176,3 +176,31 @@ def test_hqc128_full_size_properties(oracle, method):
     got2 = dec.decode_batch(msg[perm], early_exit=True)
     assert np.array_equal(got2["bits"], got["bits"][perm]) and np.array_equal(got2["iters"], got["iters"][perm])
     dec.close()
+
+
+def test_hqc256_tanh_sample(oracle):
+    """BASELINE config-3 graph at full size (N=57637, W=50, R=12000, E=612000), tanh rule,
+    50 fixed iterations: a 6-codeword sample against the oracle (f32 same-order and the
+    float64 ratio-domain reference form)."""
+    import json, os
+
+    trials = importlib.import_module("sca-ldpc_amd.trials")
+    rows = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "hqc_first_rows.json")))
+    H, Hin, _ = S.codes.hqc_bench_graph("hqc256", rows["N57637_W50_s0"])
+    assert (H.m, H.n, H.nnz) == (12000, 69637, 612000)
+    N, omega, eps = 57637, 131, 0.05
+    msg, ys = trials.hqc_trials(Hin, omega, eps, 70)
+    probs = trials.hqc_priors(N, Hin.m, omega, eps)
+    dec = bp.bp_decoder(H, max_iter=50, bp_method="product_sum", channel_probs=probs)
+    got = dec.decode_batch(msg, early_exit=False, want_llr=True)
+    sub = {k: v[:6] for k, v in got.items()}
+    ref = oracle.bp_decode_batch(H, probs, msg[:6], 1, 50, "tanh_complement", dtype="f32", threads=6, early_exit=False)
+    compare(sub, ref, "product_sum")
+    ref64 = oracle.bp_decode_batch(H, probs, msg[:6], 1, 50, "product_sum", dtype="f64", threads=6, early_exit=False)
+    conv = ref64["converged"].astype(bool)  # chaotic never-converging trials excluded from the f64 comparison
+    compare_with_reference_form({k: v[conv] for k, v in sub.items()}, {k: v[conv] for k, v in ref64.items()})
+    # whole batch: converged flags are truthful
+    e = got["bits"] ^ msg
+    c = got["converged"].astype(bool)
+    assert np.array_equal(H.syndrome(e[c]), msg[c][:, N:])
+    dec.close()

@@ -65,7 +65,7 @@ def test_fer_doctest():
     assert succ == 1
 
 
-@pytest.mark.parametrize("batch", [1, 70, 300])
+@pytest.mark.parametrize("batch", [1, 70, 300, 1024])
 def test_config4_vs_oracle(oracle, golden, batch):
     """BASELINE config 4 shape: 150x450 regular+identity (seed 1), Q=3, 5 iterations; noisy pmfs."""
     g = S.TannerGraph.from_coo(golden["generators"]["regular_identity_300_150_3_6_s1"])
