@@ -222,3 +222,116 @@ def official_example(seed, runs, error_rate=None, error_file=None, bp_decoder=No
     rng = codes.make_random_state(seed)
     ep = ErrorsProvider(error_rate, error_file, rng)
     return simulate_frame_error_rate(codes.rep_code_graph(13), ep, runs, rng, bp_decoder)
+
+
+# -- the attack loop's side of the decode path -------------------------
+class HqcCheckAccumulator:
+    """The check-accumulation half of the reference's attack loop, sparse and incremental.
+
+    The reference keeps `H` dense and grows it with `np.vstack([H, Hgen[bit_n]])` per oracle
+    answer (simulate/hqc.py:885-908), then rebuilds `[H | I]` and a fresh decoder from the dense
+    matrix on every decode (hqc.py:680,694; every DECODE_EVERY answers, hqc.py:972-980) -- O(R(N+R))
+    per decode.  Here a check is W+1 appended CSR entries (row `bit_n` of circulant(first_row),
+    then its identity column), and a decode hands the CSR arrays to the library as they stand:
+    O(E) per decode, nothing dense, the same result as `hqc_decode`.
+    """
+
+    def __init__(self, N, first_row_support, weight_of_y, bp_decoder=None, max_iter=100, decode_every=0):
+        self.N = int(N)
+        self.k = np.sort(np.asarray(first_row_support, dtype=np.int64))
+        self.omega = int(weight_of_y)
+        self.bp_decoder = bp_decoder
+        self.max_iter = max_iter
+        self.decode_every = int(decode_every)
+        self._rows = []  # sorted supports of Hin rows
+        self.checks = []  # (value, certainty)
+        self.decoder_stats = []
+        self.num_oracle_calls = 0
+        self._previous_decoding = 0
+
+    def __len__(self):
+        return len(self.checks)
+
+    def add_check(self, bit_n, check, certainty):
+        """hqc.py:885-908: append row `bit_n` of Hgen with its measured value."""
+        self._rows.append(np.sort((int(bit_n) - self.k) % self.N))
+        self.checks.append((int(bool(check)), float(certainty)))
+
+    def graph(self):
+        """H = [Hin | I_R] as a TannerGraph, built from the appended rows (never dense)."""
+        R = len(self._rows)
+        W = self.k.size
+        rows = np.repeat(np.arange(R), W + 1)
+        cols = np.concatenate([np.concatenate([r, [self.N + i]]) for i, r in enumerate(self._rows)]) if R else np.zeros(0, np.int64)
+        return TannerGraph(R, self.N + R, rows, cols)
+
+    def decode(self, y_sparse):
+        """hqc.py:661-759 on the accumulated checks; appends the stats row (hqc.py:750-758)."""
+        R = len(self.checks)
+        H = self.graph()
+        probs = np.concatenate(
+            [np.full(self.N, len(y_sparse) / self.N), np.array([1 - p for (_, p) in self.checks], dtype=np.float64)]
+        )
+        with np.errstate(divide="ignore"):
+            bpd = (self.bp_decoder or _default_bp())(H, max_iter=self.max_iter, bp_method="product_sum", channel_probs=probs)
+        cvals = np.array([c for (c, _) in self.checks], dtype=np.uint8)
+        msg = np.concatenate([np.zeros(self.N, dtype=np.uint8), cvals])
+        decoded = bpd.decode_batch(msg[None, :], early_exit=True, input_vector_type="received_vector")["bits"][0]
+        if hasattr(bpd, "close"):
+            bpd.close()
+        success, stats = hqc_stats(self.N, decoded, cvals, y_sparse)
+        row = {"checks": R, "oracle_calls": self.num_oracle_calls}
+        row.update({k: v for k, v in stats.items() if k != "checks"})
+        self.decoder_stats.append(row)
+        return success
+
+    def add_checks(self, bits, check_value, y_sparse):
+        """hqc.py:953-984: add (bit_n, certainty) pairs, decoding every `decode_every` checks.
+        Returns True as soon as a decode succeeds, else False."""
+        for bit_n, certainty in bits:
+            self.add_check(bit_n, check_value, certainty)
+            R = len(self.checks)
+            if self.decode_every and R % self.decode_every == 0 and self._previous_decoding != R:
+                self._previous_decoding = R
+                if self.decode(y_sparse):
+                    return True
+        return False
+
+
+STATS_COLUMNS = ["label", "alg", "weight", "epsilon0", "epsilon1", "checks", "oracle_calls", "unsatisfied", "good_flips",
+                 "bad_flips", "found_bad_satisfied_checks", "found_bad_unsatisfied_checks", "success"]  # fmt: skip
+
+
+def write_decoder_stats_csv(path, decoder_stats, label, alg, weight, epsilon):
+    """The CSV `main.py hqc_simulate --csv-output` produces (main.py:146-156 from
+    hqc.py:245-264): static columns label/alg/weight/epsilon0/epsilon1, then the stats
+    fields; header only when the file is new, rows appended otherwise -- the format
+    `visualize.load_data` reads (visualize.py:102-119)."""
+    import csv
+    import os
+
+    new = not os.path.exists(path)
+    with open(path, "a" if not new else "w", newline="") as f:
+        w = csv.writer(f)
+        if new:
+            w.writerow(STATS_COLUMNS)
+        for row in decoder_stats:
+            w.writerow([label, alg, weight, epsilon[0], epsilon[1]] + [row[c] for c in STATS_COLUMNS[5:]])
+
+
+def kyber_channel_probabilities(s_distr, ssum_distr, sum_weight, check_blocks, eta=2, block_len=256, num_blocks=3):
+    """Input layout of the Kyber decoders (simulate/kyber.py:362-376): secret-coefficient
+    pmfs [num_blocks*block_len, 2*eta+1] and row-sum pmfs [block_len*check_blocks,
+    2*sum_weight*eta+1], the latter REVERSED so that every row of H sums to 0."""
+    assert len(s_distr) == num_blocks and len(s_distr[0]) == block_len
+    ssum_len = block_len * check_blocks
+    assert len(ssum_distr) == ssum_len
+    B = sum_weight * eta
+    channel_output = np.zeros((block_len * num_blocks, 2 * eta + 1), dtype=np.float32)
+    channel_output_sum = np.zeros((ssum_len, 2 * B + 1), dtype=np.float32)
+    for j in range(num_blocks):
+        for i in range(block_len):
+            channel_output[i + j * block_len] = s_distr[j][i]
+    for i in range(ssum_len):
+        channel_output_sum[i] = np.asarray(ssum_distr[i])[::-1]
+    return channel_output, channel_output_sum

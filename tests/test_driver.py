@@ -94,3 +94,46 @@ def test_hqc_stats_counters():
     ok, st = drv.hqc_stats(6, np.array([0, 1, 1, 0, 0, 0, 0, 1, 1]), np.array([1, 0, 1], dtype=np.uint8), [1, 4])
     assert not ok and st["good_flips"] == 1 and st["bad_flips"] == 1 and st["unsatisfied"] == 2
     assert st["found_bad_satisfied_checks"] == 1 and st["found_bad_unsatisfied_checks"] == 1
+
+
+def test_incremental_accumulator_equals_batch_hqc_decode(golden, tmp_path):
+    """8f-3: checks appended one at a time (sparse) decode exactly like hqc_decode on the
+    stacked matrix, stats rows and CSV format as the reference writes them."""
+    from test_oracle_pins import sparse_times_sparse
+
+    t = golden["hqc_decode_tests"]["toy"]
+    N, y, r1 = t["N"], t["y_sparse"], t["first_row"]
+    yr = set(sparse_times_sparse(y, r1, N))
+    acc = drv.HqcCheckAccumulator(N, r1, len(y), bp_decoder=OracleBp, decode_every=5)
+    order = list(np.random.RandomState(1).permutation(N))
+    done = acc.add_checks([(b, 1.0) for b in order if b in yr], 1, y) or acc.add_checks(
+        [(b, 1.0) for b in order if b not in yr], 0, y
+    )
+    assert done and acc.decoder_stats[-1]["success"]
+    # the graph built incrementally is the stacked [Hin | I]
+    bits = [b for b in order if b in yr] + [b for b in order if b not in yr]
+    R = len(acc)
+    Hin = S.codes.hqc_check_graph(r1, N, bits[:R])
+    assert np.array_equal(acc.graph().to_dense(), Hin.with_identity().to_dense())
+    ok, stats = drv.hqc_decode(N, Hin, acc.checks, y, bp_decoder=OracleBp)
+    last = acc.decoder_stats[-1]
+    assert ok and all(stats[k] == last[k] for k in stats)
+    # CSV: header once, rows appended (main.py:150-156)
+    f = tmp_path / "stats.csv"
+    drv.write_decoder_stats_csv(str(f), acc.decoder_stats, "lbl", "Hqc128", 3, (1.0, 1.0))
+    drv.write_decoder_stats_csv(str(f), acc.decoder_stats[:1], "lbl", "Hqc128", 3, (1.0, 1.0))
+    lines = f.read_text().strip().splitlines()
+    assert lines[0].split(",") == drv.STATS_COLUMNS and len(lines) == 1 + len(acc.decoder_stats) + 1
+    import pandas as pd
+
+    df = pd.read_csv(f)  # what visualize.load_data does first (visualize.py:104)
+    assert {"good_flips", "bad_flips", "found_bad_unsatisfied_checks", "found_bad_satisfied_checks", "oracle_calls",
+            "unsatisfied"} <= set(df.columns)
+
+
+def test_kyber_channel_probabilities_layout():
+    s = np.random.RandomState(0).dirichlet(np.ones(5), size=(3, 256))
+    ss = np.random.RandomState(1).dirichlet(np.ones(25), size=512)
+    co, cs = drv.kyber_channel_probabilities(s, ss, 6, 2)
+    assert co.shape == (768, 5) and cs.shape == (512, 25) and co.dtype == np.float32
+    assert np.allclose(co[256 + 7], s[1][7]) and np.allclose(cs[3], ss[3][::-1])

@@ -56,3 +56,20 @@ def test_hqc_decode(golden, which, all_checks):
     ok, stats = drv.hqc_decode(N, Hin, checks, y)
     ok2, stats2 = drv.hqc_decode(N, Hin, checks, y, bp_decoder=OracleBp)
     assert ok is golden["hqc_decode_tests"]["expected"][which] and stats == stats2
+
+
+def test_incremental_accumulator_full_example(golden):
+    """hqc.py:1277-1311 driven through the incremental accumulator on the real decoder:
+    rows appended one by one, decode every 50 checks, success once enough are in."""
+    from test_oracle_pins import sparse_times_sparse
+
+    t = golden["hqc_decode_tests"]["full"]
+    N, y, r1 = t["N"], t["y_sparse"], t["first_row"]
+    yr = sparse_times_sparse(y, r1, N)
+    acc = drv.HqcCheckAccumulator(N, r1, len(y), decode_every=50)
+    found = acc.add_checks([(b, 1.0) for b in yr], 1, y)
+    if not found:  # the doctest decodes once with all of them
+        found = acc.decode(y)
+    assert found
+    assert [r["checks"] for r in acc.decoder_stats][:3] == [50, 100, 150]
+    assert acc.decoder_stats[-1]["good_flips"] == len(y) and acc.decoder_stats[-1]["bad_flips"] == 0

@@ -154,3 +154,21 @@ def test_errors():
         cls(H.astype(np.int64), 2)
     with pytest.raises(AttributeError):
         qary.decoder_class("NotADecoder")
+
+
+def test_min_sum_is_safe_from_many_threads(oracle, golden):
+    """The reference releases the GIL and calls one decoder object from a thread pool
+    (simulate/decode.py:247-262, pydecoder.rs:55): concurrent min_sum calls on ONE object
+    must all return the right answer."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    g = S.TannerGraph.from_coo(golden["generators"]["regular_identity_300_150_3_6_s1"])
+    dec = qary.decoder_class("DecoderN450R150V3C7B1")(g.to_dense(np.int8), 5)
+    rng = np.random.RandomState(2)
+    p = 1 / 3
+    good, bad = np.array([p, 1.75 * p, 0.25 * p]), np.array([p, 0.25 * p, 1.75 * p])
+    pmfs = [np.where((rng.rand(450) < 0.03)[:, None], bad, good).astype(np.float32) for _ in range(24)]
+    with ThreadPoolExecutor(8) as ex:
+        outs = list(ex.map(dec.min_sum, pmfs))
+    ref = oracle.qary_min_sum_batch(g, 3, np.stack(pmfs), 5, threads=4)
+    assert all(o == [int(x) for x in r] for o, r in zip(outs, ref))
