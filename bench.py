@@ -66,10 +66,15 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback in the product path)")
+    # Rehearsal knobs (one-GPU box only): several ranks on one device over gloo.  The real
+    # multi-GPU run uses one device per rank and backend nccl (= RCCL).
+    if os.environ.get("BENCH_FORCE_DEVICE") is not None:
+        local = int(os.environ["BENCH_FORCE_DEVICE"])
+    backend = os.environ.get("BENCH_BACKEND", "nccl")
     torch.cuda.set_device(local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        dist.init_process_group(backend, rank=rank, world_size=world)
 
     S = importlib.import_module("sca-ldpc_amd")
     bp = importlib.import_module("sca-ldpc_amd.bp")
@@ -88,7 +93,7 @@ def main():
         msg, ys = trials.hqc_trials(Hin, omega, args.eps, batch, base_seed=2, first_index=rank * batch)
 
     if args.workload == "hqc128_mc":
-        return mc_sweep(args, S, bp, lib, trials, H, N, omega, R, E, probs, iters, method, rank, world, local, dist)
+        return mc_sweep(args, S, bp, lib, trials, H, N, omega, R, E, probs, iters, method, rank, world, local, dist, backend)
     dec = bp.bp_decoder(H, max_iter=iters, bp_method=method, channel_probs=probs)
     if args.tile_group:
         dec.set_tile_group(args.tile_group)
@@ -117,7 +122,7 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     if world > 1:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
 
@@ -130,7 +135,7 @@ def main():
     # success statistics + the one end-of-run collective
     shard = importlib.import_module("sca-ldpc_amd.shard")
     ok = trials.success(d_out.cpu().numpy(), ys, N).astype(np.uint8)
-    ok_all = shard.gather_results(ok, batch * world, rank, world, device=dev)  # RCCL all_gather when world > 1
+    ok_all = shard.gather_results(ok, batch * world, rank, world, device=dev if backend == "nccl" else None)  # RCCL all_gather
     succ = float(ok_all.mean())
     conv = float(d_conv.float().mean().item())
 
@@ -197,7 +202,7 @@ def main():
         dist.destroy_process_group()
 
 
-def mc_sweep(args, S, bp, lib, trials, H, N, omega, R, E, probs, iters, method, rank, world, local, dist):
+def mc_sweep(args, S, bp, lib, trials, H, N, omega, R, E, probs, iters, method, rank, world, local, dist, backend):
     """BASELINE config 5: `--trials` synthetic hqc.decode() trials sharded over the ranks by
     GLOBAL trial index (results independent of the GPU count), generated, decoded (early
     exit, max_iter 100) and compared on the device in sub-batches of `--batch`; one gather
@@ -224,11 +229,12 @@ def mc_sweep(args, S, bp, lib, trials, H, N, omega, R, E, probs, iters, method, 
     its = np.concatenate(its) if its else np.zeros(0, np.int32)
     dev = torch.device("cuda", local)
     if world > 1:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
-    all_succ = shard.gather_results(succ, args.trials, rank, world, device=dev)
-    all_its = shard.gather_results(its, args.trials, rank, world, device=dev)
+    gdev = dev if backend == "nccl" else None
+    all_succ = shard.gather_results(succ, args.trials, rank, world, device=gdev)
+    all_its = shard.gather_results(its, args.trials, rank, world, device=gdev)
     if rank == 0:
         updates = 2.0 * E * float(all_its.astype(np.int64).sum())
         print(json.dumps({
