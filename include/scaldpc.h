@@ -109,6 +109,10 @@ int scaldpc_bp_time_kernels(scaldpc_bp *h, int32_t iters, int32_t method, float 
 /* Tuning knob: codeword tiles (64 codewords each) per cache-resident group; 0 = auto
  * (largest group whose in-place message array stays within ~200 MB of Infinity Cache). */
 int scaldpc_bp_set_tile_group(scaldpc_bp *h, int32_t tiles);
+/* Number of codewords the last early-exit call re-decoded in its compact second pass
+ * (stragglers of mostly-converged tile groups; results are identical either way;
+ * environment SCALDPC_COMPACT_AFTER=0 disables the pass, =k moves the decision point). */
+int scaldpc_bp_last_compacted(scaldpc_bp *h, int64_t *count);
 void scaldpc_bp_destroy(scaldpc_bp *h);
 
 /* ------------------------------------------- Monte-Carlo helpers on the device (K6) */

@@ -48,6 +48,8 @@ def _declare(lib):
     ]  # fmt: skip
     lib.scaldpc_bp_time_kernels.argtypes = [vp, C.c_int32, C.c_int32, C.c_float, vp, p(C.c_float), p(C.c_int32)]
     lib.scaldpc_bp_set_tile_group.argtypes = [vp, C.c_int32]
+    lib.scaldpc_bp_last_compacted.argtypes = [vp, p(C.c_int64)]
+    lib.scaldpc_bp_last_compacted.restype = C.c_int
     lib.scaldpc_bp_destroy.argtypes = [vp]
     lib.scaldpc_bp_destroy.restype = None
     lib.scaldpc_mc_fer_run.argtypes = [

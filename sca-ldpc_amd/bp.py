@@ -232,6 +232,12 @@ class BpDecoder:
         )
         return {"success": succ, "iters": iters, "msg": msg, "y": y}
 
+    def last_compacted(self):
+        """Codewords the last early-exit call re-decoded in its compact second pass."""
+        c = C.c_int64()
+        _lib.check(self._lib.scaldpc_bp_last_compacted(self._h, C.byref(c)))
+        return int(c.value)
+
     def set_tile_group(self, tiles):
         _lib.check(self._lib.scaldpc_bp_set_tile_group(self._h, int(tiles)))
 

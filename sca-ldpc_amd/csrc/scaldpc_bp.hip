@@ -620,6 +620,77 @@ __global__ __launch_bounds__(64) void k_mc_result(const u64 *__restrict__ diff, 
     if (out_iters) out_iters[b] = iters[b];
 }
 
+// ---------------------------------------------------------------------------
+// Straggler compaction (early-exit runs).  Codewords are independent, so the ones a
+// group has not converged after a few iterations can be re-decoded FROM THEIR INPUTS in
+// dense tiles of their own -- bit-identical results, without dragging 64-codeword tiles
+// that are mostly finished through the remaining iterations.  These kernels move the
+// per-codeword bits / values between the original tiles and the compact ones.
+// ids[slot] = original codeword (or -1), slot_of[codeword] = compact slot (or -1).
+// ---------------------------------------------------------------------------
+// dst[t2][x] bit c2 = src[id>>6][x] bit (id&63), id = ids[64 t2 + c2].  grid (ceil(len/64), T2), block 256.
+__global__ __launch_bounds__(256) void k_gather_planes(const u64 *__restrict__ src, int len,
+                                                       const int *__restrict__ ids, u64 *__restrict__ dst)
+{
+    const int lane = threadIdx.x & 63;
+    const int x0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 16;
+    const int t2 = blockIdx.y;
+    if (x0 >= len) return;
+    const int id = ids[(size_t)t2 * TW + lane];
+    const int nx = min(16, len - x0);
+    for (int j = 0; j < nx; j++) {
+        const int bit = id >= 0 ? (int)((src[(size_t)(id >> 6) * len + x0 + j] >> (id & 63)) & 1) : 0;
+        const u64 w = __ballot(bit);
+        if (lane == 0) dst[(size_t)t2 * len + x0 + j] = w;
+    }
+}
+
+// dst[t][x] bits of the codewords with slot_of >= 0 are replaced by src2[slot>>6][x] bit (slot&63).
+// grid (ceil(len/64), T), block 256.
+__global__ __launch_bounds__(256) void k_scatter_planes(u64 *__restrict__ dst, int len,
+                                                        const int *__restrict__ slot_of,
+                                                        const u64 *__restrict__ src2)
+{
+    const int lane = threadIdx.x & 63;
+    const int x0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 16;
+    const int t = blockIdx.y;
+    if (x0 >= len) return;
+    const int sl = slot_of[(size_t)t * TW + lane];
+    const u64 mask = __ballot(sl >= 0);
+    if (mask == 0) return;
+    const int nx = min(16, len - x0);
+    for (int j = 0; j < nx; j++) {
+        const int bit = sl >= 0 ? (int)((src2[(size_t)(sl >> 6) * len + x0 + j] >> (sl & 63)) & 1) : 0;
+        const u64 w = __ballot(bit);
+        if (lane == 0) {
+            const size_t o = (size_t)t * len + x0 + j;
+            dst[o] = (dst[o] & ~mask) | (w & mask);
+        }
+    }
+}
+
+// iteration counters and converged bits back to the original positions.  grid T, block 64.
+__global__ __launch_bounds__(64) void k_scatter_state(int *__restrict__ iters, u64 *__restrict__ conv,
+                                                      const int *__restrict__ slot_of,
+                                                      const int *__restrict__ iters2, const u64 *__restrict__ conv2)
+{
+    const int t = blockIdx.x, c = threadIdx.x;
+    const int sl = slot_of[(size_t)t * TW + c];
+    if (sl >= 0) iters[(size_t)t * TW + c] = iters2[sl];
+    const int bit = sl >= 0 ? (int)((conv2[sl >> 6] >> (sl & 63)) & 1) : 0;
+    const u64 w = __ballot(bit), mask = __ballot(sl >= 0);
+    if (c == 0 && mask) conv[t] = (conv[t] & ~mask) | (w & mask);
+}
+
+// posteriors back to the original positions.  grid (n, T), block 64.
+__global__ __launch_bounds__(64) void k_scatter_post(float *__restrict__ post, int n, const int *__restrict__ slot_of,
+                                                     const float *__restrict__ post2)
+{
+    const int v = blockIdx.x, t = blockIdx.y, c = threadIdx.x;
+    const int sl = slot_of[(size_t)t * TW + c];
+    if (sl >= 0) post[((size_t)t * n + v) * TW + c] = post2[((size_t)(sl >> 6) * n + v) * TW + (sl & 63)];
+}
+
 struct HostBuckets {
     Buckets bk;
     std::vector<int> list;
@@ -664,6 +735,13 @@ struct scaldpc_bp {
     uint8_t *d_succ = nullptr;
     size_t cap_mc = 0, cap_ylist = 0, cap_succ = 0, cap_diff = 0;
     bool thr_valid = false;
+    // compact second pass over stragglers (early-exit runs)
+    int cap_tiles2 = 0;
+    u64 *d_synd2 = nullptr, *d_hard2 = nullptr, *d_done2 = nullptr, *d_conv2 = nullptr, *d_unsat2 = nullptr;
+    int *d_iters2 = nullptr, *d_ids = nullptr, *d_slot_of = nullptr;
+    float *d_post2 = nullptr;
+    size_t cap_post2 = 0, cap_slot_of = 0;
+    long stat_deferred = 0;  // codewords re-decoded by the compact pass in the last call
     int identity_from = -1;  // n - m if the last m columns of H are I_m (H = [Hin | I]), else -1
     hipStream_t own_stream = nullptr;
     int last_group = 0;  // tiles of the last decoded group (for scaldpc_bp_time_kernels)
@@ -814,9 +892,65 @@ float alpha_for(float alpha, int it)
     return alpha == 0.0f ? (float)(1.0 - std::pow(2.0, -1.0 * it)) : alpha;
 }
 
+struct TileState {
+    const u64 *synd;
+    u64 *hard, *done, *conv, *unsat;
+    int *iters;
+    float *post;
+};
+
+// All iterations of the tile group [g0, g0+g) of `st`.  With defer_after > 0 the group
+// stops after that many iterations when at most half of its codewords are still running
+// and reports *deferred = true: those codewords go to the compact pass.
+int iterate_group(scaldpc_bp *h, const TileState &st, int g0, int g, int max_iter, int method, float alpha, bool early,
+                  int defer_after, hipStream_t s, bool *deferred)
+{
+    const int poll_every = 4;
+    const int skip = early ? 1 : 0;
+    const u64 *synd_g = st.synd + (size_t)g0 * h->m;
+    u64 *hard_g = st.hard + (size_t)g0 * h->n;
+    u64 *done_g = st.done + g0, *conv_g = st.conv + g0, *unsat_g = st.unsat + g0;
+    int *iters_g = st.iters + (size_t)g0 * TW;
+    float *post_g = st.post ? st.post + (size_t)g0 * h->n * TW : nullptr;
+    *deferred = false;
+    if (h->E) {
+        hipLaunchKernelGGL(k_init_msg, dim3((unsigned)((h->E + 3) / 4), g), dim3(256), 0, s, h->d_col_idx, h->d_prior,
+                           h->d_msg, h->E);
+        LAUNCH_CHECK();
+    }
+    if (early) SC_HIP(hipMemsetAsync(h->d_remaining, 0, sizeof(int) * ((size_t)max_iter + 2), s));
+    for (int it = 1; it <= max_iter; it++) {
+        const bool last = it == max_iter;
+        SC_TRY(launch_check(h, method, alpha_for(alpha, it), g, synd_g, done_g, skip, s));
+        SC_TRY(launch_var(h, g, post_g, hard_g, done_g, skip, (early || last) ? 1 : 0, s));
+        if (early || last) {
+            hipLaunchKernelGGL(k_parity<true>, dim3((h->m + 255) / 256, g), dim3(256), 0, s, h->d_row_ptr, h->d_col_idx,
+                               hard_g, h->m, h->n, const_cast<u64 *>(synd_g), unsat_g, (const u64 *)done_g);
+            LAUNCH_CHECK();
+            hipLaunchKernelGGL(k_finalize, dim3(g), dim3(64), 0, s, it, early ? 1 : 0, done_g, conv_g, unsat_g, iters_g,
+                               h->d_remaining + it);
+            LAUNCH_CHECK();
+        }
+        const bool defer_point = defer_after > 0 && it == defer_after;
+        if (early && !last && (it % poll_every == 0 || it == 1 || defer_point)) {
+            SC_HIP(hipMemcpyAsync(h->h_remaining + it, h->d_remaining + it, sizeof(int), hipMemcpyDeviceToHost, s));
+            SC_HIP(hipStreamSynchronize(s));
+            const int rem = h->h_remaining[it];
+            if (rem == 0) break;
+            if (defer_point && 2 * rem <= g * TW) {
+                *deferred = true;
+                break;
+            }
+        }
+    }
+    return 0;
+}
+
 // The decode proper, on inputs already staged as planes (h->d_synd; h->d_recv when the
 // caller wants e XOR v): state reset, then all iterations of one cache-resident tile
-// group after the other.  Results stay on the device (h->d_hard / d_post / d_conv / d_iters).
+// group after the other; in early-exit runs, stragglers of mostly-converged groups are
+// re-decoded from their inputs in a compact second pass (identical results).
+// Results stay on the device (h->d_hard / d_post / d_conv / d_iters).
 int run_core(scaldpc_bp *h, int batch, int T, int G, int max_iter, int method, float alpha, bool early,
              bool want_post, hipStream_t s)
 {
@@ -824,47 +958,92 @@ int run_core(scaldpc_bp *h, int batch, int T, int G, int max_iter, int method, f
                        h->d_iters);
     LAUNCH_CHECK();
     SC_HIP(hipMemsetAsync(h->d_hard, 0, sizeof(u64) * (size_t)T * h->n, s));
+    h->last_group = std::min(G, T);
+    h->stat_deferred = 0;
 
-    // ---- iterate, one cache-resident tile group at a time ----------------------
-    const int poll_every = 4;
-    const int skip = early ? 1 : 0;
+    int defer_after = 0;
+    if (early) {
+        defer_after = 8;
+        if (const char *e = getenv("SCALDPC_COMPACT_AFTER")) defer_after = atoi(e);
+        if (max_iter <= 2 * defer_after) defer_after = 0;  // nothing to gain
+    }
+    const TileState st{h->d_synd, h->d_hard, h->d_done, h->d_conv, h->d_unsat, h->d_iters,
+                       want_post ? h->d_post : nullptr};
+    std::vector<char> deferred_tile(T, 0);
+    bool any = false;
     for (int g0 = 0; g0 < T; g0 += G) {
         const int g = std::min(G, T - g0);
-        const u64 *synd_g = h->d_synd + (size_t)g0 * h->m;
-        u64 *hard_g = h->d_hard + (size_t)g0 * h->n;
-        u64 *done_g = h->d_done + g0;
-        u64 *conv_g = h->d_conv + g0;
-        u64 *unsat_g = h->d_unsat + g0;
-        int *iters_g = h->d_iters + (size_t)g0 * TW;
-        float *post_g = want_post ? h->d_post + (size_t)g0 * h->n * TW : nullptr;
-        if (h->E) {
-            hipLaunchKernelGGL(k_init_msg, dim3((unsigned)((h->E + 3) / 4), g), dim3(256), 0, s, h->d_col_idx,
-                               h->d_prior, h->d_msg, h->E);
-            LAUNCH_CHECK();
+        bool d = false;
+        SC_TRY(iterate_group(h, st, g0, g, max_iter, method, alpha, early, defer_after, s, &d));
+        if (d) {
+            any = true;
+            for (int t = g0; t < g0 + g; t++) deferred_tile[t] = 1;
         }
-        if (early) SC_HIP(hipMemsetAsync(h->d_remaining, 0, sizeof(int) * ((size_t)max_iter + 2), s));
-        for (int it = 1; it <= max_iter; it++) {
-            const bool last = it == max_iter;
-            SC_TRY(launch_check(h, method, alpha_for(alpha, it), g, synd_g, done_g, skip, s));
-            SC_TRY(launch_var(h, g, post_g, hard_g, done_g, skip, (early || last) ? 1 : 0, s));
-            if (early || last) {
-                hipLaunchKernelGGL(k_parity<true>, dim3((h->m + 255) / 256, g), dim3(256), 0, s, h->d_row_ptr,
-                                   h->d_col_idx, hard_g, h->m, h->n, const_cast<u64 *>(synd_g), unsat_g,
-                                   (const u64 *)done_g);
-                LAUNCH_CHECK();
-                hipLaunchKernelGGL(k_finalize, dim3(g), dim3(64), 0, s, it, early ? 1 : 0, done_g, conv_g, unsat_g,
-                                   iters_g, h->d_remaining + it);
-                LAUNCH_CHECK();
-            }
-            if (early && !last && (it % poll_every == 0 || it == 1)) {
-                SC_HIP(hipMemcpyAsync(h->h_remaining + it, h->d_remaining + it, sizeof(int), hipMemcpyDeviceToHost, s));
-                SC_HIP(hipStreamSynchronize(s));
-                if (h->h_remaining[it] == 0) break;
+    }
+    if (!any) return 0;
+
+    // ---- compact second pass ---------------------------------------------------------
+    std::vector<u64> done_h(T);
+    SC_HIP(hipMemcpyAsync(done_h.data(), h->d_done, sizeof(u64) * T, hipMemcpyDeviceToHost, s));
+    SC_HIP(hipStreamSynchronize(s));
+    std::vector<int> ids, slot_of((size_t)T * TW, -1);
+    for (int t = 0; t < T; t++) {
+        if (!deferred_tile[t]) continue;
+        for (int c = 0; c < TW; c++) {
+            const long b = (long)t * TW + c;
+            if (b < batch && !((done_h[t] >> c) & 1)) {
+                slot_of[b] = (int)ids.size();
+                ids.push_back((int)b);
             }
         }
     }
-    h->last_group = std::min(G, T);
-
+    const int batch2 = (int)ids.size();
+    if (batch2 == 0) return 0;
+    h->stat_deferred = batch2;
+    const int T2 = (batch2 + TW - 1) / TW;
+    ids.resize((size_t)T2 * TW, -1);
+    if (T2 > h->cap_tiles2) {
+        dev_free(h->d_synd2); dev_free(h->d_hard2); dev_free(h->d_done2); dev_free(h->d_conv2); dev_free(h->d_unsat2);
+        dev_free(h->d_iters2); dev_free(h->d_ids);
+        h->cap_tiles2 = 0;
+        SC_TRY(dev_alloc(&h->d_synd2, (size_t)T2 * h->m));
+        SC_TRY(dev_alloc(&h->d_hard2, (size_t)T2 * h->n));
+        SC_TRY(dev_alloc(&h->d_done2, (size_t)T2));
+        SC_TRY(dev_alloc(&h->d_conv2, (size_t)T2));
+        SC_TRY(dev_alloc(&h->d_unsat2, (size_t)T2));
+        SC_TRY(dev_alloc(&h->d_iters2, (size_t)T2 * TW));
+        SC_TRY(dev_alloc(&h->d_ids, (size_t)T2 * TW));
+        h->cap_tiles2 = T2;
+    }
+    SC_TRY(grow(&h->d_slot_of, &h->cap_slot_of, (size_t)T * TW));
+    if (want_post) SC_TRY(grow(&h->d_post2, &h->cap_post2, (size_t)T2 * h->n * TW));
+    SC_HIP(hipMemcpyAsync(h->d_ids, ids.data(), sizeof(int) * ids.size(), hipMemcpyHostToDevice, s));
+    SC_HIP(hipMemcpyAsync(h->d_slot_of, slot_of.data(), sizeof(int) * slot_of.size(), hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(k_gather_planes, dim3((h->m + 63) / 64, T2), dim3(256), 0, s, h->d_synd, h->m, h->d_ids,
+                       h->d_synd2);
+    LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_init_state, dim3(T2), dim3(64), 0, s, batch2, max_iter, h->d_done2, h->d_conv2, h->d_unsat2,
+                       h->d_iters2);
+    LAUNCH_CHECK();
+    SC_HIP(hipMemsetAsync(h->d_hard2, 0, sizeof(u64) * (size_t)T2 * h->n, s));
+    const TileState st2{h->d_synd2, h->d_hard2, h->d_done2, h->d_conv2, h->d_unsat2, h->d_iters2,
+                        want_post ? h->d_post2 : nullptr};
+    const int G2 = std::min(G, T2);
+    for (int g0 = 0; g0 < T2; g0 += G2) {
+        bool d = false;
+        SC_TRY(iterate_group(h, st2, g0, std::min(G2, T2 - g0), max_iter, method, alpha, early, 0, s, &d));
+    }
+    hipLaunchKernelGGL(k_scatter_planes, dim3((h->n + 63) / 64, T), dim3(256), 0, s, h->d_hard, h->n, h->d_slot_of,
+                       h->d_hard2);
+    LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_scatter_state, dim3(T), dim3(64), 0, s, h->d_iters, h->d_conv, h->d_slot_of, h->d_iters2,
+                       h->d_conv2);
+    LAUNCH_CHECK();
+    if (want_post) {
+        hipLaunchKernelGGL(k_scatter_post, dim3(h->n, T), dim3(64), 0, s, h->d_post, h->n, h->d_slot_of, h->d_post2);
+        LAUNCH_CHECK();
+    }
+    SC_HIP(hipStreamSynchronize(s));  // ids / slot_of are locals
     return 0;
 }
 
@@ -984,6 +1163,14 @@ int scaldpc_bp_set_channel_probs(scaldpc_bp *h, const double *probs)
     h->h_probs.assign(probs, probs + h->n);
     h->thr_valid = false;
     h->have_prior = true;
+    return 0;
+}
+
+int scaldpc_bp_last_compacted(scaldpc_bp *h, int64_t *count)
+{
+    if (!h || !count) return fail(SCALDPC_EINVAL, "NULL argument");
+    std::lock_guard<std::mutex> lk(h->mu);
+    *count = h->stat_deferred;
     return 0;
 }
 
@@ -1288,6 +1475,8 @@ void scaldpc_bp_destroy(scaldpc_bp *h)
     dev_free(h->d_conv); dev_free(h->d_unsat); dev_free(h->d_iters); dev_free(h->d_remaining);
     dev_free(h->d_in); dev_free(h->d_out_bits); dev_free(h->d_out_conv); dev_free(h->d_out_llr);
     dev_free(h->d_out_iters);
+    dev_free(h->d_synd2); dev_free(h->d_hard2); dev_free(h->d_done2); dev_free(h->d_conv2); dev_free(h->d_unsat2);
+    dev_free(h->d_iters2); dev_free(h->d_ids); dev_free(h->d_slot_of); dev_free(h->d_post2);
     dev_free(h->d_thr); dev_free(h->d_mc); dev_free(h->d_diff); dev_free(h->d_ylist); dev_free(h->d_succ);
     if (h->h_remaining) (void)hipHostFree(h->h_remaining);
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);

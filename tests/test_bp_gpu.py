@@ -204,3 +204,30 @@ def test_hqc256_tanh_sample(oracle):
     c = got["converged"].astype(bool)
     assert np.array_equal(H.syndrome(e[c]), msg[c][:, N:])
     dec.close()
+
+
+@pytest.mark.parametrize("method", ["min_sum", "product_sum"])
+def test_straggler_compaction_is_invisible(oracle, method, monkeypatch):
+    """Early-exit runs re-decode the stragglers of mostly-converged tile groups in a compact
+    second pass.  Results (decisions, posteriors, iteration counts, flags) must be identical
+    with the pass disabled, and equal to the oracle's one-codeword-at-a-time decode."""
+    H, Hin, probs, msg, y = hqc_instance(997, 9, 450, 6, 0.03, 700, seed=21)
+    dec = bp.bp_decoder(H, max_iter=60, bp_method=method, channel_probs=probs)
+    dec.set_tile_group(3)  # several groups, a ragged last one
+    a = dec.decode_batch(msg, early_exit=True, want_llr=True)
+    assert 0 < dec.last_compacted() < 350  # the pass actually ran, on a minority
+    monkeypatch.setenv("SCALDPC_COMPACT_AFTER", "0")
+    b = dec.decode_batch(msg, early_exit=True, want_llr=True)
+    assert dec.last_compacted() == 0
+    for k in ("bits", "llr", "iters", "converged"):
+        assert np.array_equal(a[k], b[k]), k
+    ref = oracle.bp_decode_batch(H, probs, msg, 1, 60, ORACLE_METHOD[method], dtype="f32", threads=8)
+    compare(a, ref, method)
+    # the Monte-Carlo entry point goes through the same core
+    monkeypatch.delenv("SCALDPC_COMPACT_AFTER")
+    r1 = dec.mc_hqc_run(500, omega=6, eps=0.03, seed=5)
+    n1 = dec.last_compacted()
+    monkeypatch.setenv("SCALDPC_COMPACT_AFTER", "0")
+    r2 = dec.mc_hqc_run(500, omega=6, eps=0.03, seed=5)
+    assert n1 > 0 and np.array_equal(r1["success"], r2["success"]) and np.array_equal(r1["iters"], r2["iters"])
+    dec.close()
