@@ -403,6 +403,149 @@ __global__ __launch_bounds__(256) void k_check_tanh(Buckets bk, const int *__res
 }
 
 // ---------------------------------------------------------------------------
+// LDS-resident decoder for small graphs (the reference's own FER commands: n = 13 ... 1500,
+// E <= 4500, main.py:189-276).  When a codeword's whole message state fits one CU's LDS
+// (2 E floats + n + m bytes), ONE launch decodes the batch: workgroup = codeword, the
+// messages never leave LDS, all iterations and the H e == s early exit run inside the
+// kernel (no per-iteration launches, no host polling, no HBM/cache traffic at all).
+// Threads take rows in the check phase and columns in the variable phase and sweep their
+// edges sequentially in the reference package's order, so every value is bit-identical
+// to the streaming kernels' (same operations, same order, same device math).
+//   LDS: msg[E] (in place v2c <-> c2v), scr[E] (prefix sums / prefix products),
+//        hard[n], synd[m], recv[n] (received-vector mode), flag.
+// grid = batch, block = 256.
+// ---------------------------------------------------------------------------
+template <int METHOD>  // SCALDPC_BP_PRODUCT_SUM / SCALDPC_BP_MIN_SUM
+__global__ __launch_bounds__(256) void k_bp_small(const int *__restrict__ row_ptr, const int *__restrict__ col_idx,
+                                                  const int *__restrict__ col_ptr, const int *__restrict__ csc_edge,
+                                                  const float *__restrict__ prior, int m, int n, int E,
+                                                  const uint8_t *__restrict__ in, int kind, int max_iter, float alpha0,
+                                                  int early, uint8_t *__restrict__ out_bits,
+                                                  float *__restrict__ out_llr, int *__restrict__ out_iters,
+                                                  uint8_t *__restrict__ out_conv)
+{
+    extern __shared__ float sm[];
+    float *msg = sm, *scr = sm + E;
+    uint8_t *hard = (uint8_t *)(scr + E);
+    uint8_t *synd = hard + n;
+    uint8_t *recv = synd + m;  // n bytes, received-vector mode only
+    __shared__ int flag;
+    const int b = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
+
+    if (kind == SCALDPC_IN_SYNDROME) {
+        for (int r = tid; r < m; r += nt) synd[r] = in[(size_t)b * m + r] & 1;
+    } else {
+        for (int v = tid; v < n; v += nt) recv[v] = in[(size_t)b * n + v] & 1;
+        __syncthreads();
+        for (int r = tid; r < m; r += nt) {
+            uint8_t p = 0;
+            for (int e = row_ptr[r]; e < row_ptr[r + 1]; e++) p ^= recv[col_idx[e]];
+            synd[r] = p;
+        }
+    }
+    for (int e = tid; e < E; e += nt) msg[e] = prior[col_idx[e]];
+    for (int v = tid; v < n; v += nt) hard[v] = 0;
+    __syncthreads();
+
+    int it_done = max_iter, conv = 0;
+    for (int it = 1; it <= max_iter; it++) {
+        const bool last = it == max_iter;
+        // ---- check nodes ----
+        if (METHOD == SCALDPC_BP_MIN_SUM) {
+            const float alpha = alpha0 == 0.0f ? (float)(1.0 - exp2(-(double)it)) : alpha0;
+            const float nalpha = -alpha;
+            for (int r = tid; r < m; r += nt) {
+                const int e0 = row_ptr[r], e1 = row_ptr[r + 1];
+                float m1 = FLT_MAX, m2 = FLT_MAX;
+                int ix = e0;
+                unsigned par = synd[r];
+                for (int e = e0; e < e1; e++) {
+                    const float x = msg[e];
+                    const float a = fabsf(x);
+                    par ^= (unsigned)(x <= 0.0f);
+                    const bool lt = a < m1;
+                    m2 = lt ? m1 : ((a < m2) ? a : m2);
+                    ix = lt ? e : ix;
+                    m1 = lt ? a : m1;
+                }
+                for (int e = e0; e < e1; e++) {
+                    const unsigned nb = msg[e] <= 0.0f;
+                    msg[e] = ((e == ix) ? m2 : m1) * ((par ^ nb) ? nalpha : alpha);
+                }
+            }
+        } else {
+            for (int r = tid; r < m; r += nt) {
+                const int e0 = row_ptr[r], e1 = row_ptr[r + 1];
+                float U = 0.0f;
+                unsigned par = synd[r];
+                for (int e = e0; e < e1; e++) {
+                    const float x = msg[e];
+                    scr[e] = U;
+                    par ^= (unsigned)(x < 0.0f);
+                    const float u = tanh_compl(fabsf(x));
+                    U = U + u * (1.0f - U);
+                }
+                U = 0.0f;
+                for (int e = e1 - 1; e >= e0; e--) {
+                    const float x = msg[e];
+                    const float pk = scr[e];
+                    const float Ut = pk + U * (1.0f - pk);
+                    const float Lm = llr_from_compl(Ut);
+                    msg[e] = ((par ^ (unsigned)(x < 0.0f)) & 1u) ? -Lm : Lm;
+                    const float u = tanh_compl(fabsf(x));
+                    U = U + u * (1.0f - U);
+                }
+            }
+        }
+        __syncthreads();
+        // ---- variable nodes ----
+        const bool outs = early || last;
+        for (int v = tid; v < n; v += nt) {
+            const int c0 = col_ptr[v], c1 = col_ptr[v + 1];
+            float temp = prior[v];
+            for (int t = c0; t < c1; t++) {
+                const int e = csc_edge[t];
+                scr[e] = temp;
+                temp += msg[e];
+            }
+            float suf = 0.0f;
+            for (int t = c1 - 1; t >= c0; t--) {
+                const int e = csc_edge[t];
+                const float mk = msg[e];
+                msg[e] = scr[e] + suf;
+                suf += mk;
+            }
+            if (outs) {
+                hard[v] = temp <= 0.0f;
+                if (out_llr) out_llr[(size_t)b * n + v] = temp;
+            }
+        }
+        if (tid == 0) flag = 0;
+        __syncthreads();
+        // ---- H e == s ? ----
+        if (outs) {
+            for (int r = tid; r < m; r += nt) {
+                uint8_t p = synd[r];
+                for (int e = row_ptr[r]; e < row_ptr[r + 1]; e++) p ^= hard[col_idx[e]];
+                if (p) flag = 1;
+            }
+            __syncthreads();
+            conv = !flag;
+            if (conv && early) {
+                it_done = it;
+                break;
+            }
+        }
+    }
+    for (int v = tid; v < n; v += nt)
+        out_bits[(size_t)b * n + v] = hard[v] ^ (kind == SCALDPC_IN_RECEIVED ? recv[v] : (uint8_t)0);
+    if (tid == 0) {
+        if (out_iters) out_iters[b] = it_done;
+        if (out_conv) out_conv[b] = (uint8_t)conv;
+    }
+}
+
+// ---------------------------------------------------------------------------
 // K4  variable-node update + posterior + hard decision, in place.
 //   prefix : v2c_k = prior + sum_{k'<k} c2v_k'      (ascending row)
 //   total  : L = prior + sum_k c2v_k ; e = [L <= 0]
@@ -1206,6 +1349,59 @@ int scaldpc_bp_decode_batch(scaldpc_bp *h, const uint8_t *in, int32_t input_kind
     if (T > 65535) return fail(SCALDPC_EINVAL, "batch %d too large for one call (max %d)", batch, 65535 * TW);
     const int G = (h->tile_group > 0) ? std::min(h->tile_group, T) : auto_group(h, T);
     const int len = input_kind == SCALDPC_IN_SYNDROME ? h->m : h->n;
+
+    // Small graph: the LDS-resident single-launch decoder (k_bp_small).
+    const size_t small_lds = (size_t)2 * h->E * sizeof(float) + (size_t)2 * h->n + h->m + 64;
+    const char *force = getenv("SCALDPC_PATH");  // "stream" / "lds" pin a path (tests)
+    const bool small_fits = small_lds <= 60 * 1024 && h->E > 0;
+    if (force && !strcmp(force, "lds") && !small_fits)
+        return fail(SCALDPC_EINVAL, "SCALDPC_PATH=lds but the graph needs %zu B of LDS", small_lds);
+    if (small_fits && !(force && !strcmp(force, "stream"))) {
+        const uint8_t *din = in;
+        uint8_t *dbits = out_bits, *dconv = out_conv;
+        float *dllr = out_llr;
+        int *diters = out_iters;
+        if (!dev_io) {
+            SC_TRY(grow(&h->d_in, &h->cap_in, (size_t)batch * len));
+            SC_HIP(hipMemcpyAsync(h->d_in, in, (size_t)batch * len, hipMemcpyHostToDevice, s));
+            din = h->d_in;
+            SC_TRY(grow(&h->d_out_bits, &h->cap_out_bits, (size_t)batch * h->n));
+            dbits = h->d_out_bits;
+            if (out_llr) {
+                SC_TRY(grow(&h->d_out_llr, &h->cap_out_llr, (size_t)batch * h->n));
+                dllr = h->d_out_llr;
+            }
+            if ((size_t)batch > h->cap_out_b) {
+                dev_free(h->d_out_iters);
+                dev_free(h->d_out_conv);
+                h->cap_out_b = 0;
+                SC_TRY(dev_alloc(&h->d_out_iters, (size_t)batch));
+                SC_TRY(dev_alloc(&h->d_out_conv, (size_t)batch));
+                h->cap_out_b = batch;
+            }
+            diters = out_iters ? h->d_out_iters : nullptr;
+            dconv = out_conv ? h->d_out_conv : nullptr;
+        }
+#define SMALL_LAUNCH(M)                                                                                            \
+    hipLaunchKernelGGL(k_bp_small<M>, dim3(batch), dim3(256), small_lds, s, h->d_row_ptr, h->d_col_idx, h->d_col_ptr, \
+                       h->d_csc_edge, h->d_prior, h->m, h->n, (int)h->E, din, input_kind, max_iter, alpha,          \
+                       early ? 1 : 0, dbits, dllr, diters, dconv)
+        if (method == SCALDPC_BP_MIN_SUM)
+            SMALL_LAUNCH(SCALDPC_BP_MIN_SUM);
+        else
+            SMALL_LAUNCH(SCALDPC_BP_PRODUCT_SUM);
+#undef SMALL_LAUNCH
+        LAUNCH_CHECK();
+        if (!dev_io) {
+            SC_HIP(hipMemcpyAsync(out_bits, dbits, (size_t)batch * h->n, hipMemcpyDeviceToHost, s));
+            if (out_llr) SC_HIP(hipMemcpyAsync(out_llr, dllr, sizeof(float) * (size_t)batch * h->n, hipMemcpyDeviceToHost, s));
+            if (out_iters) SC_HIP(hipMemcpyAsync(out_iters, diters, sizeof(int) * (size_t)batch, hipMemcpyDeviceToHost, s));
+            if (out_conv) SC_HIP(hipMemcpyAsync(out_conv, dconv, (size_t)batch, hipMemcpyDeviceToHost, s));
+        }
+        h->stat_deferred = 0;
+        if (!(flags & SCALDPC_F_ASYNC)) SC_HIP(hipStreamSynchronize(s));
+        return 0;
+    }
     SC_TRY(ensure_workspace(h, T, G, out_llr != nullptr, max_iter));
 
     // ---- stage input --------------------------------------------------------

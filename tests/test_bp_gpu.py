@@ -13,6 +13,18 @@ pytestmark = pytest.mark.gpu
 bp = importlib.import_module("sca-ldpc_amd.bp")
 
 
+@pytest.fixture(autouse=True, params=["auto", "stream"])
+def decode_path(request, monkeypatch):
+    """Every test runs twice: with the library's own choice (small graphs -> the LDS-resident
+    single-launch decoder, large ones -> the streaming kernels) and with the streaming kernels
+    forced, so both implementations face the same oracle."""
+    if request.param == "stream":
+        monkeypatch.setenv("SCALDPC_PATH", "stream")
+    else:
+        monkeypatch.delenv("SCALDPC_PATH", raising=False)
+    return request.param
+
+
 def run_both(oracle, H, probs, x, kind, max_iter, method, early, alpha=1.0):
     dec = bp.bp_decoder(H, max_iter=max_iter, bp_method=method, channel_probs=probs, ms_scaling_factor=alpha)
     got = dec.decode_batch(x, early_exit=early, want_llr=True)
@@ -207,11 +219,12 @@ def test_hqc256_tanh_sample(oracle):
 
 
 @pytest.mark.parametrize("method", ["min_sum", "product_sum"])
-def test_straggler_compaction_is_invisible(oracle, method, monkeypatch):
+def test_straggler_compaction_is_invisible(oracle, method, monkeypatch, decode_path):
     """Early-exit runs re-decode the stragglers of mostly-converged tile groups in a compact
     second pass.  Results (decisions, posteriors, iteration counts, flags) must be identical
     with the pass disabled, and equal to the oracle's one-codeword-at-a-time decode."""
     H, Hin, probs, msg, y = hqc_instance(997, 9, 450, 6, 0.03, 700, seed=21)
+    monkeypatch.setenv("SCALDPC_PATH", "stream")  # compaction belongs to the streaming path
     dec = bp.bp_decoder(H, max_iter=60, bp_method=method, channel_probs=probs)
     dec.set_tile_group(3)  # several groups, a ragged last one
     a = dec.decode_batch(msg, early_exit=True, want_llr=True)
@@ -231,3 +244,27 @@ def test_straggler_compaction_is_invisible(oracle, method, monkeypatch):
     r2 = dec.mc_hqc_run(500, omega=6, eps=0.03, seed=5)
     assert n1 > 0 and np.array_equal(r1["success"], r2["success"]) and np.array_equal(r1["iters"], r2["iters"])
     dec.close()
+
+
+def test_lds_path_is_taken_and_agrees_with_streaming(monkeypatch):
+    """Small graph: `SCALDPC_PATH=lds` must be accepted (the graph fits) and give the same
+    bits / posteriors / iteration counts as the streaming kernels, for both methods and both
+    input kinds; a large graph must refuse `lds`."""
+    H, Hin, probs, msg, y = hqc_instance(499, 7, 200, 5, 0.02, 150, seed=4)
+    for method in ("min_sum", "product_sum"):
+        for kind_in in (msg, H.syndrome(np.concatenate([y, np.zeros((150, 200), np.uint8)], axis=1))):
+            out = {}
+            for path in ("lds", "stream"):
+                monkeypatch.setenv("SCALDPC_PATH", path)
+                dec = bp.bp_decoder(H, max_iter=25, bp_method=method, channel_probs=probs)
+                out[path] = dec.decode_batch(kind_in, early_exit=True, want_llr=True)
+                dec.close()
+            for k in ("bits", "llr", "iters", "converged"):
+                assert np.array_equal(out["lds"][k], out["stream"][k]), (method, k)
+    import json, os
+    rows = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "hqc_first_rows.json")))
+    big, _, _ = S.codes.hqc_bench_graph("hqc128", rows["N17669_W50_s0"], R=300)
+    monkeypatch.setenv("SCALDPC_PATH", "lds")
+    dec = bp.bp_decoder(big, error_rate=0.01, max_iter=3)
+    with pytest.raises(ValueError, match="LDS"):
+        dec.decode_batch(np.zeros((1, big.m), dtype=np.uint8))
