@@ -27,6 +27,7 @@
 #define SFX f64
 #define RLOG log
 #define REXP exp
+#define RFMA fma
 #define RTANH tanh
 #define RABS fabs
 #define RBIG 1e308
@@ -35,6 +36,7 @@
 #undef SFX
 #undef RLOG
 #undef REXP
+#undef RFMA
 #undef RTANH
 #undef RABS
 #undef RBIG
@@ -43,6 +45,7 @@
 #define SFX f32
 #define RLOG logf
 #define REXP expf
+#define RFMA fmaf
 #define RTANH tanhf
 #define RABS fabsf
 #define RBIG FLT_MAX
@@ -51,6 +54,7 @@
 #undef SFX
 #undef RLOG
 #undef REXP
+#undef RFMA
 #undef RTANH
 #undef RABS
 #undef RBIG

@@ -21,7 +21,7 @@
  *   method 2  "product_sum_log"  LLR domain tanh rule, textbook form
  *   method 3  the tanh rule in COMPLEMENT form -- the build's fp32 kernel order:
  *             u_k = 1 - tanh(|x_k|/2) = 2/(exp|x_k| + 1); exclusive products kept as
- *             U = 1 - prod(1-u) through U' = U + u(1-U); |c2v| = log(2/U - 1).
+ *             U = 1 - prod(1-u) through U' = fma(u, 1-U, U); |c2v| = log(2/U - 1).
  *             Same function as methods 0/2, but free of the 1-x cancellation that
  *             makes the textbook form saturate at |L| ~ 17 in fp32.
  *
@@ -101,17 +101,17 @@ int FN(oracle_bp_decode)(int m, int n, const int32_t *row_ptr, const int32_t *co
                     esgn[e] = sgn;
                     const REAL u = (REAL)2 / (REXP(RABS(b2c[e])) + (REAL)1);
                     ubuf[e] = u;
-                    U = U + u * ((REAL)1 - U);
+                    U = RFMA(u, (REAL)1 - U, U);
                     if (b2c[e] < (REAL)0) sgn += 1;
                 }
                 U = (REAL)0;
                 sgn = 0;
                 for (int e = row_ptr[i + 1] - 1; e >= row_ptr[i]; e--) {
-                    const REAL Ut = c2b[e] + U * ((REAL)1 - c2b[e]);
+                    const REAL Ut = RFMA(U, (REAL)1 - c2b[e], c2b[e]);
                     esgn[e] += sgn;
                     const REAL Lm = RLOG((REAL)2 / Ut - (REAL)1);
                     c2b[e] = (esgn[e] & 1) ? -Lm : Lm;
-                    U = U + ubuf[e] * ((REAL)1 - U);
+                    U = RFMA(ubuf[e], (REAL)1 - U, U);
                     if (b2c[e] < (REAL)0) sgn += 1;
                 }
             }

@@ -300,42 +300,49 @@ __global__ __launch_bounds__(256) void k_check_minsum(const int *__restrict__ ro
 // errors (|dL| stays ~1e-6 relative, tests/helpers.compare states the tolerance).
 __device__ __forceinline__ float tanh_compl(float a)  // 1 - tanh(a/2) = 2 / (e^a + 1), a >= 0
 {
-    return 2.0f * __builtin_amdgcn_rcpf(__expf(a) + 1.0f);
+    // raw v_exp_f32: e^a >= 1 here, so the denormal fix-ups of __expf are dead weight
+    return 2.0f * __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(a * 1.44269504088896340736f) + 1.0f);
 }
-__device__ __forceinline__ float llr_from_compl(float U)  // 2 atanh(1 - U) = log(2/U - 1)
+__device__ __forceinline__ float llr_from_compl(float U)  // 2 atanh(1 - U) = log(2/U - 1), U in [0, 1]
 {
-    return __logf(2.0f * __builtin_amdgcn_rcpf(U) - 1.0f);
+    // 2/U - 1 >= 1: raw v_log_f32 needs no denormal handling either
+    return __builtin_amdgcn_logf(fmaf(2.0f, __builtin_amdgcn_rcpf(U), -1.0f)) * 0.69314718055994530942f;
 }
+// U' = U + u (1 - U), one rounding (the oracle's method 3 uses fmaf in the same places)
+__device__ __forceinline__ float compl_step(float U, float u) { return fmaf(u, 1.0f - U, U); }
 
-template <int MAXDEG>
-__device__ __forceinline__ void check_tanh_row(float *p, int deg, unsigned sbit)
+template <int DEG>
+__device__ __forceinline__ void check_tanh_row(float *p, unsigned sbit)
 {
-    float uu[MAXDEG], pre[MAXDEG];
+    // EXACT degree: straight-line code, no per-edge branches (a predicated `k < deg` unroll
+    // makes every edge its own basic block, and the compiler then waits for all memory
+    // traffic at each block entry).
+    // uu[k]: first the input x_k, then u_k >= 0 carrying the SIGN BIT of x_k (a -0.0 input
+    // counts as negative here; it forces every other output of the row to +-0, so only
+    // the sign of exact zeros can differ from the `x < 0` convention), finally the output.
+    float uu[DEG], pre[DEG];
 #pragma unroll
-    for (int k = 0; k < MAXDEG; k++)
-        if (k < deg) uu[k] = p[(size_t)k * TW];
-    u64 neg = 0;
+    for (int k = 0; k < DEG; k++) uu[k] = p[(size_t)k * TW];
+    unsigned acc = sbit << 31;  // running XOR of sign bits, syndrome folded in
     float U = 0.0f;
 #pragma unroll
-    for (int k = 0; k < MAXDEG; k++)
-        if (k < deg) {
-            const float x = uu[k];
-            neg |= (u64)(x < 0.0f) << k;
-            const float u = tanh_compl(fabsf(x));
-            uu[k] = u;
-            pre[k] = U;
-            U = U + u * (1.0f - U);
-        }
-    const unsigned tot = ((unsigned)__popcll(neg) ^ sbit) & 1u;
+    for (int k = 0; k < DEG; k++) {
+        const unsigned xb = __float_as_uint(uu[k]);
+        acc ^= xb;
+        const float u = tanh_compl(fabsf(uu[k]));
+        uu[k] = __uint_as_float(__float_as_uint(u) | (xb & 0x80000000u));
+        pre[k] = U;
+        U = compl_step(U, u);
+    }
     U = 0.0f;
 #pragma unroll
-    for (int k = MAXDEG - 1; k >= 0; k--)
-        if (k < deg) {
-            const float Ut = pre[k] + U * (1.0f - pre[k]);
-            const float Lm = llr_from_compl(Ut);
-            p[(size_t)k * TW] = ((tot ^ (unsigned)(neg >> k)) & 1u) ? -Lm : Lm;
-            U = U + uu[k] * (1.0f - U);
-        }
+    for (int k = DEG - 1; k >= 0; k--) {
+        const float Ut = compl_step(pre[k], U);  // pre + U (1 - pre)
+        const float Lm = llr_from_compl(Ut);
+        const unsigned sg = (acc ^ __float_as_uint(uu[k])) & 0x80000000u;  // parity of the OTHER inputs
+        U = compl_step(U, fabsf(uu[k]));
+        p[(size_t)k * TW] = __uint_as_float(__float_as_uint(Lm) ^ sg);
+    }
 }
 
 // Any-degree fallback: the forward sweep parks Upre in a scratch array (the reference
@@ -350,17 +357,17 @@ __device__ __forceinline__ void check_tanh_row_generic(float *p, float *sc, int 
         sc[(size_t)k * TW] = U;
         par ^= (unsigned)(x < 0.0f);
         const float u = tanh_compl(fabsf(x));
-        U = U + u * (1.0f - U);
+        U = compl_step(U, u);
     }
     U = 0.0f;
     for (int k = deg - 1; k >= 0; k--) {
         const float x = p[(size_t)k * TW];
         const float pk = sc[(size_t)k * TW];
-        const float Ut = pk + U * (1.0f - pk);
+        const float Ut = compl_step(pk, U);
         const float Lm = llr_from_compl(Ut);
         p[(size_t)k * TW] = ((par ^ (unsigned)(x < 0.0f)) & 1u) ? -Lm : Lm;
         const float u = tanh_compl(fabsf(x));
-        U = U + u * (1.0f - U);
+        U = compl_step(U, u);
     }
 }
 
@@ -387,19 +394,24 @@ __global__ __launch_bounds__(256) void k_check_tanh(Buckets bk, const int *__res
     const size_t base = ((size_t)tl * E + e0) * TW + lane;
     float *p = msg + base;
     const unsigned sbit = (unsigned)(synd[(size_t)tl * m + r] >> lane) & 1u;
-    switch (bk.maxd[b]) {
-        case 2: check_tanh_row<2>(p, deg, sbit); break;
-        case 4: check_tanh_row<4>(p, deg, sbit); break;
-        case 8: check_tanh_row<8>(p, deg, sbit); break;
-        case 16: check_tanh_row<16>(p, deg, sbit); break;
-        case 32:
-            if constexpr (CAP >= 32) check_tanh_row<32>(p, deg, sbit);
-            break;
-        case 64:
-            if constexpr (CAP >= 64) check_tanh_row<64>(p, deg, sbit);
-            break;
-        default: check_tanh_row_generic(p, scratch + base, deg, sbit);
+    // dispatch on the row's exact degree (wave-uniform); CAP bounds what is compiled in
+#define TR(D)                                                  \
+    case D:                                                    \
+        if constexpr (D <= CAP) check_tanh_row<D>(p, sbit);    \
+        break;
+#define TR8(D) TR(D) TR(D + 1) TR(D + 2) TR(D + 3) TR(D + 4) TR(D + 5) TR(D + 6) TR(D + 7)
+    if (bk.maxd[b] == 0) {
+        check_tanh_row_generic(p, scratch + base, deg, sbit);
+    } else {
+        switch (deg) {
+            TR(1) TR(2) TR(3) TR(4) TR(5) TR(6) TR(7)
+            TR8(8) TR8(16) TR8(24) TR8(32) TR8(40) TR8(48) TR8(56)
+            TR(64)
+            default: break;
+        }
     }
+#undef TR8
+#undef TR
 }
 
 // ---------------------------------------------------------------------------
@@ -483,17 +495,17 @@ __global__ __launch_bounds__(256) void k_bp_small(const int *__restrict__ row_pt
                     scr[e] = U;
                     par ^= (unsigned)(x < 0.0f);
                     const float u = tanh_compl(fabsf(x));
-                    U = U + u * (1.0f - U);
+                    U = compl_step(U, u);
                 }
                 U = 0.0f;
                 for (int e = e1 - 1; e >= e0; e--) {
                     const float x = msg[e];
                     const float pk = scr[e];
-                    const float Ut = pk + U * (1.0f - pk);
+                    const float Ut = compl_step(pk, U);
                     const float Lm = llr_from_compl(Ut);
                     msg[e] = ((par ^ (unsigned)(x < 0.0f)) & 1u) ? -Lm : Lm;
                     const float u = tanh_compl(fabsf(x));
-                    U = U + u * (1.0f - U);
+                    U = compl_step(U, u);
                 }
             }
         }
@@ -550,7 +562,9 @@ __global__ __launch_bounds__(256) void k_bp_small(const int *__restrict__ row_pt
 //   prefix : v2c_k = prior + sum_{k'<k} c2v_k'      (ascending row)
 //   total  : L = prior + sum_k c2v_k ; e = [L <= 0]
 //   suffix : v2c_k += sum_{k'>k} c2v_k'             (accumulated from the last edge)
-// Column values live in registers (unrolled to MAXD, predicated on the uniform degree).
+// Column values live in registers (unrolled to MAXD, predicated on the uniform degree: for this
+// gather kernel the lower register count of the bucketed form (70 VGPRs, 7 waves/SIMD) beats
+// exact-degree straight-line code (131 VGPRs): 68.6 vs 74.9 us).
 // Returns the posterior L.
 // ---------------------------------------------------------------------------
 template <int MAXD>
@@ -913,6 +927,8 @@ void build_buckets(const std::vector<int> &deg, const int *bounds, int nb, bool 
         const int i = bk.nb++;
         bk.maxd[i] = b < nb ? bounds[b] : 0;
         if (b == nb) out.has_generic = true;
+        // neighbouring waves of a launch should run the same exact-degree code path
+        std::stable_sort(tmp[b].begin(), tmp[b].end(), [&](int x, int y) { return deg[x] < deg[y]; });
         bk.off[i] = (int)out.list.size();
         bk.cnt[i] = (int)tmp[b].size();
         bk.blk[i + 1] = bk.blk[i] + (bk.cnt[i] + 3) / 4;
