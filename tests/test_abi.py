@@ -61,8 +61,15 @@ def test_dropin_modules_import():
     assert ldpc.bp_decoder.__name__ == "BpDecoder"
     assert ldpc.codes.rep_code(13).shape == (12, 13)
     assert simulate_rs.DecoderN450R150V3C7B1.Q == 3 and simulate_rs.DecoderN1280R512SW6.BSUM == 12
-    try:
-        simulate_rs.Hqc128
-        assert False
-    except AttributeError:
-        pass
+    # the import line of simulate/hqc.py:23 must work; constants yes, cryptography no
+    from simulate_rs import Hqc128, Hqc192, Hqc256
+
+    assert (Hqc128.params("N"), Hqc128.params("omega"), Hqc128.params("N1") * Hqc128.params("N2")) == (17669, 66, 17664)
+    assert (Hqc192.params("N"), Hqc256.params("N"), Hqc256.params("DELTA")) == (35851, 57637, 29)
+    assert Hqc128.name() == "Hqc128"
+    import pytest
+
+    with pytest.raises(NotImplementedError):
+        Hqc128.keypair()
+    with pytest.raises(ValueError):
+        Hqc128.params("nope")
