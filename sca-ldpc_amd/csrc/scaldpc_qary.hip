@@ -221,6 +221,181 @@ __global__ void k_q_special_check(const int *__restrict__ row_ptr, float *msg, i
     for (int q = 0; q < QS; q++) msg[((size_t)(e0 + nb) * W + q) * Bp + b] = Bs[(size_t)q * T + tid];
 }
 
+// ---------------------------------------------------------------------------
+// Small batches (single `min_sum` calls, the reference's usual pattern): lane = codeword
+// would leave 63 lanes idle while one walks Q^(DC-1) assignments.  Here a WAVE owns one
+// (check, codeword): the lanes split the assignment space (assignment c goes to lane
+// c mod 64, stepped through mixed-radix digits), each keeps private running minima in LDS
+// ([slot][lane], conflict free), and the 64 partial minima of every slot are combined with
+// wave shuffles.  min is exact and every S is summed in the same order as before, so the
+// messages are bit-identical to the lane = codeword kernels'.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ float wave_min(float v)
+{
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v = fminf(v, __shfl_xor(v, off));
+    return v;
+}
+
+// generic Decoder check (decoder.rs:585-631).  grid (R, batch), block 64.
+// LDS: A[k*Q] floats (shared), fin[k*Q] + num[k] bytes (shared), Bt[k*Q][64] floats (per lane).
+__global__ __launch_bounds__(64) void k_q_check_wave(const int *__restrict__ row_ptr, float *msg, int Q, int B, long Bp,
+                                                     int maxdc, int *__restrict__ err)
+{
+    extern __shared__ unsigned char smem[];
+    const int lane = threadIdx.x;
+    float *A = (float *)smem;
+    float *Bt = A + maxdc * Q;
+    unsigned char *fin = (unsigned char *)(Bt + (size_t)maxdc * Q * 64);
+    unsigned char *num = fin + maxdc * Q;
+    const int c = blockIdx.x;
+    const long b = blockIdx.y;
+    const int e0 = row_ptr[c], k = row_ptr[c + 1] - e0;
+    if (k == 0) {
+        if (lane == 0) atomicMax(err, QERR_NO_CONFIG);
+        return;
+    }
+    for (int i = lane; i < k * Q; i += 64) A[i] = msg[((size_t)(e0 + i / Q) * Q + i % Q) * Bp + b];
+    for (int i = 0; i < k * Q; i++) Bt[(size_t)i * 64 + lane] = INFINITY;
+    __syncthreads();
+    if (lane < k) {
+        int cnt = 0;
+        for (int q = 0; q < Q; q++)
+            if (finite_f(A[lane * Q + q])) fin[lane * Q + cnt++] = (unsigned char)q;
+        num[lane] = (unsigned char)cnt;
+    }
+    __syncthreads();
+    bool bad = false;
+    unsigned long long total = 1;
+    for (int j = 0; j < k; j++) bad |= num[j] == 0;
+    for (int j = 0; j < k - 1; j++) total *= num[j];
+    if (bad) {
+        if (lane == 0) atomicMax(err, QERR_NO_FINITE);
+    } else {
+        // digits of this lane's first assignment and of the stride 64, index 0 fastest
+        u64 idx = 0, stp = 0;
+        {
+            unsigned long long a = (unsigned long long)lane, st = 64;
+            for (int j = 0; j < k - 1; j++) {
+                idx |= (u64)(a % num[j]) << (8 * j);
+                a /= num[j];
+                stp |= (u64)(st % num[j]) << (8 * j);
+                st /= num[j];
+            }
+        }
+        int nconf = 0;
+        for (unsigned long long cfg = lane; cfg < total; cfg += 64) {
+            int dsum = 0;
+            float S = 0.0f;
+            u64 qs = 0;
+            for (int j = 0; j < k - 1; j++) {
+                const int q = fin[j * Q + ((int)(idx >> (8 * j)) & 255)];
+                qs |= (u64)q << (8 * j);
+                dsum += q - B;
+                S += A[j * Q + q];
+            }
+            const int dl = -dsum;
+            if (dl >= -B && dl <= B) {
+                const int ql = dl + B;
+                qs |= (u64)ql << (8 * (k - 1));
+                S += A[(k - 1) * Q + ql];
+                if (finite_f(S)) {
+                    nconf++;
+                    for (int j = 0; j < k; j++) {
+                        const int q = (int)(qs >> (8 * j)) & 255;
+                        float *bb = &Bt[(size_t)(j * Q + q) * 64 + lane];
+                        *bb = fminf(S - A[j * Q + q], *bb);
+                    }
+                }
+            }
+            // idx += stride (mixed radix, one conditional subtraction per digit)
+            int carry = 0;
+            u64 nidx = 0;
+            for (int j = 0; j < k - 1; j++) {
+                int d = ((int)(idx >> (8 * j)) & 255) + ((int)(stp >> (8 * j)) & 255) + carry;
+                carry = d >= num[j];
+                if (carry) d -= num[j];
+                nidx |= (u64)d << (8 * j);
+            }
+            idx = nidx;
+        }
+        const u64 any = __ballot(nconf > 0);
+        if (!any && lane == 0) atomicMax(err, QERR_NO_CONFIG);
+    }
+    for (int i = 0; i < k * Q; i++) {
+        const float v = wave_min(Bt[(size_t)i * 64 + lane]);
+        if (lane == 0) msg[((size_t)(e0 + i / Q) * Q + i % Q) * Bp + b] = v;
+    }
+}
+
+// DecoderSpecial check (decoder_special.rs:506-563), wave per (check, codeword).
+// LDS: Ab[nb*QB], As[QS] floats (shared), Bb[nb*QB][64], Bs[QS][64] floats (per lane).
+__global__ __launch_bounds__(64) void k_q_special_check_wave(const int *__restrict__ row_ptr, float *msg, int B, int BSUM,
+                                                             int W, long Bp, int nbm)
+{
+    extern __shared__ unsigned char smem[];
+    const int lane = threadIdx.x;
+    const int QB = 2 * B + 1, QS = 2 * BSUM + 1;
+    float *Ab = (float *)smem;
+    float *As = Ab + nbm * QB;
+    float *Bb = As + QS;
+    float *Bs = Bb + (size_t)nbm * QB * 64;
+    const int c = blockIdx.x;
+    const long b = blockIdx.y;
+    const int e0 = row_ptr[c], k = row_ptr[c + 1] - e0, nb = k - 1;
+    for (int i = lane; i < nb * QB; i += 64) Ab[i] = msg[((size_t)(e0 + i / QB) * W + i % QB) * Bp + b];
+    for (int i = lane; i < QS; i += 64) As[i] = msg[((size_t)(e0 + nb) * W + i) * Bp + b];
+    for (int i = 0; i < nb * QB; i++) Bb[(size_t)i * 64 + lane] = INFINITY;
+    for (int i = 0; i < QS; i++) Bs[(size_t)i * 64 + lane] = INFINITY;
+    __syncthreads();
+    unsigned long long total = 1;
+    for (int j = 0; j < nb; j++) total *= QB;
+    u64 dq = 0, stp = 0;
+    {
+        unsigned long long a = (unsigned long long)lane, st = 64;
+        for (int j = 0; j < nb; j++) {
+            dq |= (u64)(a % QB) << (8 * j);
+            a /= QB;
+            stp |= (u64)(st % QB) << (8 * j);
+            st /= QB;
+        }
+    }
+    for (unsigned long long cfg = lane; cfg < total; cfg += 64) {
+        int dsum = 0;
+        float S = 0.0f;
+        for (int j = 0; j < nb; j++) {
+            const int q = (int)(dq >> (8 * j)) & 255;
+            dsum += q - B;
+            S += Ab[j * QB + q];
+        }
+        const int os = -dsum + BSUM;
+        S += As[os];
+        for (int j = 0; j < nb; j++) {
+            const int q = (int)(dq >> (8 * j)) & 255;
+            float *bb = &Bb[(size_t)(j * QB + q) * 64 + lane];
+            *bb = fminf(*bb, S - Ab[j * QB + q]);
+        }
+        Bs[(size_t)os * 64 + lane] = fminf(Bs[(size_t)os * 64 + lane], S - As[os]);
+        int carry = 0;
+        u64 ndq = 0;
+        for (int j = 0; j < nb; j++) {
+            int d = ((int)(dq >> (8 * j)) & 255) + ((int)(stp >> (8 * j)) & 255) + carry;
+            carry = d >= QB;
+            if (carry) d -= QB;
+            ndq |= (u64)d << (8 * j);
+        }
+        dq = ndq;
+    }
+    for (int i = 0; i < nb * QB; i++) {
+        const float v = wave_min(Bb[(size_t)i * 64 + lane]);
+        if (lane == 0) msg[((size_t)(e0 + i / QB) * W + i % QB) * Bp + b] = v;
+    }
+    for (int i = 0; i < QS; i++) {
+        const float v = wave_min(Bs[(size_t)i * 64 + lane]);
+        if (lane == 0) msg[((size_t)(e0 + nb) * W + i) * Bp + b] = v;
+    }
+}
+
 // Variable-node update (decoder.rs:634-658 / decoder_special.rs:566-609).
 // thread = (variable, codeword); LDS: sum[Qmax][T], tmp[Qmax][T].
 __global__ void k_q_var(int v0, const int *__restrict__ col_ptr, const int *__restrict__ csc_edge,
@@ -490,9 +665,21 @@ int qary_run(scaldpc_qary *h, const float *pmf_b, const float *pmf_s, int batch,
         return fail(SCALDPC_EDEGREE, "alphabet/degree too large for the LDS-staged enumeration (%zu B per codeword)",
                     per_thread);
     const int iters = std::max(1, h->iterations);  // the loop body runs at least once (decoder.rs:578-579)
+    // small batch: wave per (check, codeword), lanes share the assignment space
+    const size_t wave_lds = h->special
+                                ? (size_t)(((h->maxdc - 1) * h->Q + h->QS) * 65) * 4
+                                : (size_t)h->maxdc * h->Q * 4 * 65 + (size_t)h->maxdc * h->Q + h->maxdc + 16;
+    bool wave_mode = batch < 32 && wave_lds <= 64 * 1024;
+    if (const char *e = getenv("SCALDPC_QARY_WAVE")) wave_mode = atoi(e) != 0 && wave_lds <= 64 * 1024;
     for (int it = 1; it <= iters; it++) {
         if (h->E) {
-            if (h->special)
+            if (wave_mode && h->special)
+                hipLaunchKernelGGL(k_q_special_check_wave, dim3(h->R, batch), dim3(64), wave_lds, s, h->d_row_ptr, h->d_msg,
+                                   h->B, h->BSUM, h->W, Bp, h->maxdc - 1);
+            else if (wave_mode)
+                hipLaunchKernelGGL(k_q_check_wave, dim3(h->R, batch), dim3(64), wave_lds, s, h->d_row_ptr, h->d_msg, h->Q,
+                                   h->B, Bp, h->maxdc, h->d_err);
+            else if (h->special)
                 hipLaunchKernelGGL(k_q_special_check, dim3(h->R, Bp / T), dim3(T), per_thread * T, s, h->d_row_ptr,
                                    h->d_msg, h->B, h->BSUM, h->W, Bp, batch, h->maxdc - 1);
             else

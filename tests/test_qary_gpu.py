@@ -172,3 +172,37 @@ def test_min_sum_is_safe_from_many_threads(oracle, golden):
         outs = list(ex.map(dec.min_sum, pmfs))
     ref = oracle.qary_min_sum_batch(g, 3, np.stack(pmfs), 5, threads=4)
     assert all(o == [int(x) for x in r] for o, r in zip(outs, ref))
+
+
+def test_wave_parallel_mode_equals_lane_mode(oracle, golden, monkeypatch):
+    """Small batches split each check's assignment space over the 64 lanes of a wave and
+    min-reduce with shuffles; large batches put one codeword per lane.  Same answers,
+    for the generic and the special decoder."""
+    import time
+
+    g = S.TannerGraph.from_coo(golden["generators"]["regular_identity_300_150_3_6_s1"])
+    rng = np.random.RandomState(8)
+    p = 1 / 3
+    good, bad = np.array([p, 1.75 * p, 0.25 * p]), np.array([p, 0.25 * p, 1.75 * p])
+    pmf = np.where((rng.rand(20, 450) < 0.05)[:, :, None], bad, good).astype(np.float32)
+    dec = qary.decoder_class("DecoderN450R150V3C7B1")(g.to_dense(np.int8), 5)
+    out = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("SCALDPC_QARY_WAVE", mode)
+        out[mode] = dec.min_sum_batch(pmf)
+    assert np.array_equal(out["0"], out["1"])
+    assert np.array_equal(out["1"], oracle.qary_min_sum_batch(g, 3, pmf, 5, threads=4))
+    gk = S.TannerGraph.from_coo(golden["generators"]["qary_qc_256_6_3_s0_cb2"])
+    r2 = np.random.RandomState(11)
+    pb = r2.dirichlet(np.ones(5), size=(2, 768)).astype(np.float32)
+    ps = r2.dirichlet(np.ones(25), size=(2, 512)).astype(np.float32)
+    dk = qary.decoder_class("DecoderN1280R512SW6")(gk.to_dense(np.int8), 2)
+    t = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("SCALDPC_QARY_WAVE", mode)
+        dk.min_sum_batch(pb, ps)
+        t0 = time.perf_counter()
+        out[mode] = dk.min_sum_batch(pb, ps)
+        t[mode] = time.perf_counter() - t0
+    assert np.array_equal(out["0"], out["1"])
+    print(f"Kyber N1280R512SW6, batch 2, 2 iterations: wave mode {t['1']*1e3:.2f} ms, lane mode {t['0']*1e3:.2f} ms")
