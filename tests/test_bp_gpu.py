@@ -268,3 +268,68 @@ def test_lds_path_is_taken_and_agrees_with_streaming(monkeypatch):
     dec = bp.bp_decoder(big, error_rate=0.01, max_iter=3)
     with pytest.raises(ValueError, match="LDS"):
         dec.decode_batch(np.zeros((1, big.m), dtype=np.uint8))
+
+
+def test_device_io_equals_host_io():
+    """SCALDPC_F_DEVICE_IO (what bench.py uses: torch tensors' data_ptr(), nothing crosses
+    PCIe) must give the same outputs as the host-buffer path, on the caller's stream."""
+    import torch
+
+    lib = importlib.import_module("sca-ldpc_amd._lib")
+    H, Hin, probs, msg, y = hqc_instance(997, 9, 450, 6, 0.03, 333, seed=31)
+    for method in ("min_sum", "product_sum"):
+        for early in (False, True):
+            dec = bp.bp_decoder(H, max_iter=20, bp_method=method, channel_probs=probs)
+            host = dec.decode_batch(msg, early_exit=early, want_llr=True)
+            d_in = torch.from_numpy(msg).cuda()
+            d_bits = torch.zeros((333, H.n), dtype=torch.uint8, device="cuda")
+            d_llr = torch.zeros((333, H.n), dtype=torch.float32, device="cuda")
+            d_it = torch.zeros(333, dtype=torch.int32, device="cuda")
+            d_cv = torch.zeros(333, dtype=torch.uint8, device="cuda")
+            st = torch.cuda.Stream()
+            with torch.cuda.stream(st):
+                dec.decode_batch_device(d_in.data_ptr(), lib.IN_RECEIVED, 333, d_bits.data_ptr(), early_exit=early,
+                                        stream=st.cuda_stream, d_out_llr=d_llr.data_ptr(), d_out_iters=d_it.data_ptr(),
+                                        d_out_conv=d_cv.data_ptr())
+            st.synchronize()
+            assert np.array_equal(d_bits.cpu().numpy(), host["bits"])
+            assert np.array_equal(d_llr.cpu().numpy(), host["llr"])
+            assert np.array_equal(d_it.cpu().numpy(), host["iters"])
+            assert np.array_equal(d_cv.cpu().numpy(), host["converged"])
+            dec.close()
+
+
+@pytest.mark.parametrize("group", [1, 2, 5])
+def test_tile_group_size_is_invisible(group, monkeypatch):
+    """Results cannot depend on how tiles are grouped for cache residency (ragged last group,
+    group larger than the batch, group of one)."""
+    monkeypatch.setenv("SCALDPC_PATH", "stream")
+    H, Hin, probs, msg, y = hqc_instance(499, 7, 200, 5, 0.02, 300, seed=4)
+    dec = bp.bp_decoder(H, max_iter=25, bp_method="min_sum", channel_probs=probs)
+    base = dec.decode_batch(msg, early_exit=True, want_llr=True)
+    dec.set_tile_group(group)
+    got = dec.decode_batch(msg, early_exit=True, want_llr=True)
+    fixed = dec.decode_batch(msg, early_exit=False, want_llr=True)
+    dec.set_tile_group(0)
+    fixed0 = dec.decode_batch(msg, early_exit=False, want_llr=True)
+    for k in ("bits", "llr", "iters", "converged"):
+        assert np.array_equal(base[k], got[k]) and np.array_equal(fixed[k], fixed0[k]), k
+    dec.close()
+
+
+def test_large_batch(oracle, monkeypatch):
+    """70 000 codewords (1094 tiles) through the streaming kernels: 64-bit indexing, grid
+    limits, many groups; spot-checked against the oracle, ends and middle."""
+    monkeypatch.setenv("SCALDPC_PATH", "stream")
+    rng = np.random.RandomState(12)
+    H = random_graph(rng, 30, 70, 0.1)
+    probs = rng.uniform(0.01, 0.1, size=H.n)
+    batch = 70_000
+    err = (rng.rand(batch, H.n) < probs[None, :]).astype(np.uint8)
+    synd = (err.astype(np.int32) @ H.to_dense().T.astype(np.int32) % 2).astype(np.uint8)
+    dec = bp.bp_decoder(H, max_iter=12, bp_method="min_sum", channel_probs=probs)
+    got = dec.decode_batch(synd, early_exit=True, want_llr=True)
+    for sl in (slice(0, 100), slice(35_000, 35_100), slice(batch - 100, batch)):
+        ref = oracle.bp_decode_batch(H, probs, synd[sl], 0, 12, "min_sum", dtype="f32", threads=4)
+        compare({k: v[sl] for k, v in got.items()}, ref, "min_sum")
+    dec.close()

@@ -56,3 +56,22 @@ def test_hqc_run_needs_identity_block():
     dec = bp.bp_decoder(g, error_rate=0.1)
     with pytest.raises(ValueError, match="Hin"):
         dec.mc_hqc_run(4, omega=2, eps=0.1, seed=1)
+
+
+def test_mc_device_outputs():
+    """The Monte-Carlo entry points with device-side outputs (SCALDPC_F_DEVICE_IO)."""
+    import ctypes as C
+
+    import torch
+
+    lib = importlib.import_module("sca-ldpc_amd._lib")
+    H, Hin, probs, _, _ = hqc_instance(499, 7, 260, 5, 0.04, 1, seed=11, flip=False)
+    dec = bp.bp_decoder(H, max_iter=40, bp_method="min_sum", channel_probs=probs)
+    host = dec.mc_hqc_run(200, omega=5, eps=0.04, seed=9)
+    d_s = torch.zeros(200, dtype=torch.uint8, device="cuda")
+    d_i = torch.zeros(200, dtype=torch.int32, device="cuda")
+    lib.check(dec._lib.scaldpc_mc_hqc_run(dec._h, 5, 0.04, 0, 200, 9, 40, lib.BP_MIN_SUM, 1.0,
+                                          lib.F_EARLY_EXIT | lib.F_DEVICE_IO, None, C.c_void_p(d_s.data_ptr()),
+                                          C.c_void_p(d_i.data_ptr()), None, None))
+    assert np.array_equal(d_s.cpu().numpy(), host["success"]) and np.array_equal(d_i.cpu().numpy(), host["iters"])
+    dec.close()
