@@ -293,6 +293,7 @@ def cpu_baseline(H, probs, msg, iters, method, E, budget_s):
         "sample": f"first {sample} codewords of the same batch, {iters} fixed iterations, f32 {om}, "
         f"{threads} OpenMP threads over codewords ({dt:.1f} s); restated CPU path, not the reference binary",
         "codewords_per_s": sample / dt,
+        "single_thread_value": 2.0 * E * iters / one,  # one codeword on one core, same code
     }
 
 
