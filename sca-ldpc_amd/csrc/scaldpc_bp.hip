@@ -290,8 +290,8 @@ __global__ __launch_bounds__(256) void k_check_minsum(const int *__restrict__ ro
 // Exact for |L| up to ~88 (then u underflows to 0 and L = +inf, which is also what
 // p = 0 priors feed in).  Same exclusive forward/backward sweep as the reference
 // package; the CPU oracle's method 3 is this sequence op for op.
-// Row values live in registers (compile-time unrolled to MAXDEG <= 64, predicated on
-// the wave-uniform degree), signs in a 64-bit mask.
+// Row values live in registers: straight-line code instantiated for the row's EXACT degree
+// (1..64, dispatched wave-uniformly), sign parity carried in the float sign bits.
 // ---------------------------------------------------------------------------
 // Device math for the tanh rule: the hardware transcendental units (v_exp_f32,
 // v_rcp_f32, v_log_f32; ~1 ulp each) instead of the ~100-instruction-per-edge
@@ -371,9 +371,11 @@ __device__ __forceinline__ void check_tanh_row_generic(float *p, float *sc, int 
     }
 }
 
-// One fused launch over all row-degree buckets.  wave = (row, tile).
-// CAP = largest unroll bound compiled in (register budget follows the widest bucket,
-// so graphs with narrow rows get the high-occupancy instantiation).
+// One fused launch over all rows (the bucket table only separates the register-resident
+// rows, degree <= 64, from the any-degree fallback; its lists are sorted by degree so that
+// neighbouring waves run the same instantiation).  wave = (row, tile).
+// CAP = largest degree compiled in (the register budget follows the widest instantiation,
+// so graphs with narrow rows get the high-occupancy build).
 // grid (bk.blk[nb], G), block 256 = 4 rows of one bucket.
 template <int CAP>
 __global__ __launch_bounds__(256) void k_check_tanh(Buckets bk, const int *__restrict__ list,
