@@ -132,6 +132,21 @@ def main():
     ms_var_pass = kt["ms_var"] / max(1, kt["launches_var"])
     swept = kt["codewords"]  # codewords per launch (tile padded)
 
+    # measured device copy ceiling on this very GPU (SURVEY.md 8d asks for it next to the
+    # datasheet peak): 1 GiB float copy, read + write bytes / time
+    src = torch.empty(256 * 1024 * 1024, dtype=torch.float32, device=dev).normal_()
+    dst = torch.empty_like(src)
+    for _ in range(2):
+        dst.copy_(src)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(10):
+        dst.copy_(src)
+    e1.record()
+    torch.cuda.synchronize()
+    copy_gbs = 2.0 * src.numel() * 4 * 10 / (e0.elapsed_time(e1) * 1e-3) / 1e9
+    del src, dst
+
     # success statistics + the one end-of-run collective
     shard = importlib.import_module("sca-ldpc_amd.shard")
     ok = trials.success(d_out.cpu().numpy(), ys, N).astype(np.uint8)
@@ -171,6 +186,7 @@ def main():
             "decode_success_rate": succ,
             "converged_rate": conv,
             "kernel_ms": {"check_per_launch": ms_check, "var_pass": ms_var_pass},
+            "hbm_copy_ceiling_GBps": copy_gbs,  # measured: 1 GiB device copy, read+write bytes/s
         }
         traffic = pmc_traffic(args.workload, batch, swept, "k_check_minsum<false>" if dominant_is_check else "k_check_tanh")
         if dominant_is_check:
