@@ -15,6 +15,19 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
 
 
+@pytest.fixture(scope="session", autouse=True)
+def _built_artefacts():
+    """Built libraries are git-ignored: make sure the HIP library (cross-compiles without a GPU)
+    and the test oracle exist before any test loads them.  A failed build fails the session
+    loudly -- there is nothing to fall back to."""
+    lib = importlib.import_module("sca-ldpc_amd._lib")
+    if not os.path.exists(lib.SO_PATH):
+        lib.build()
+    from oracle import pyoracle
+
+    pyoracle.build()
+
+
 @pytest.fixture(scope="session")
 def scaldpc():
     return importlib.import_module("sca-ldpc_amd")
