@@ -222,7 +222,7 @@ __global__ void k_q_special_check(const int *__restrict__ row_ptr, float *msg, i
 }
 
 // ---------------------------------------------------------------------------
-// Small batches (single `min_sum` calls, the reference's usual pattern): lane = codeword
+// Small and medium batches (<= 256; single `min_sum` calls are the reference's usual pattern): lane = codeword
 // would leave 63 lanes idle while one walks Q^(DC-1) assignments.  Here a WAVE owns one
 // (check, codeword): the lanes split the assignment space (assignment c goes to lane
 // c mod 64, stepped through mixed-radix digits), each keeps private running minima in LDS
@@ -669,7 +669,9 @@ int qary_run(scaldpc_qary *h, const float *pmf_b, const float *pmf_s, int batch,
     const size_t wave_lds = h->special
                                 ? (size_t)(((h->maxdc - 1) * h->Q + h->QS) * 65) * 4
                                 : (size_t)h->maxdc * h->Q * 4 * 65 + (size_t)h->maxdc * h->Q + h->maxdc + 16;
-    bool wave_mode = batch < 32 && wave_lds <= 64 * 1024;
+    // measured: wave mode 0.69 vs 3.2 ms at batch 64 (config-4 decoder), 24 vs 70 ms (Kyber SW6);
+    // a tie at batch 1024, where one codeword per lane keeps global accesses coalesced
+    bool wave_mode = batch <= 256 && wave_lds <= 64 * 1024;
     if (const char *e = getenv("SCALDPC_QARY_WAVE")) wave_mode = atoi(e) != 0 && wave_lds <= 64 * 1024;
     for (int it = 1; it <= iters; it++) {
         if (h->E) {
