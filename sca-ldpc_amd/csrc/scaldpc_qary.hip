@@ -27,6 +27,8 @@
 #include <cmath>
 #include <cstring>
 #include <mutex>
+#include <thread>
+#include <utility>
 #include <vector>
 
 using namespace scaldpc;
@@ -219,6 +221,106 @@ __global__ void k_q_special_check(const int *__restrict__ row_ptr, float *msg, i
     for (int j = 0; j < nb; j++)
         for (int q = 0; q < QB; q++) msg[((size_t)(e0 + j) * W + q) * Bp + b] = Bb[(size_t)(j * QB + q) * T + tid];
     for (int q = 0; q < QS; q++) msg[((size_t)(e0 + nb) * W + q) * Bp + b] = Bs[(size_t)q * T + tid];
+}
+
+// ---------------------------------------------------------------------------
+// Unrolled enumeration for small alphabets (the reference's own decoder sizes: Q = 3,
+// DC <= 7; also Q = 5, DC <= 5).  Every digit is a template argument, so alpha / beta live in
+// registers with compile-time indices -- no LDS, no index arithmetic.  S is built left to
+// right through the recursion (the partial sum of the first j digits is shared by all
+// assignments below it: the same additions in the same order as decoder.rs:600-610, fewer of
+// them).  No finite-support filter is needed: an assignment through a non-finite alpha has
+// S = inf or NaN, its candidates S - alpha_j are inf or NaN, and fminf never lets those
+// lower a minimum -- exactly the assignments FiniteDValueIterator / `cfg.sum.is_finite()`
+// (decoder.rs:281-401, 612) would have skipped.
+// lane = codeword, thread = (check, codeword).
+// ---------------------------------------------------------------------------
+template <int Q, int K, int J, int... D>
+struct QEnum {
+    static __device__ __forceinline__ void run(const float (&A)[K][Q], float (&Bt)[K][Q], float S, int &nconf)
+    {
+        run_q(A, Bt, S, nconf, std::make_integer_sequence<int, Q>());
+    }
+    template <int... Qs>
+    static __device__ __forceinline__ void run_q(const float (&A)[K][Q], float (&Bt)[K][Q], float S, int &nconf,
+                                                 std::integer_sequence<int, Qs...>)
+    {
+        (QEnum<Q, K, J + 1, D..., Qs>::run(A, Bt, S + A[J][Qs], nconf), ...);
+    }
+};
+// last edge: its digit is fixed by sum d = 0
+template <int Q, int K, int... D>
+struct QEnum<Q, K, K - 1, D...> {
+    static constexpr int B = (Q - 1) / 2;
+    static constexpr int dl = -((D - B) + ... + 0);
+    static __device__ __forceinline__ void run(const float (&A)[K][Q], float (&Bt)[K][Q], float S, int &nconf)
+    {
+        if constexpr (dl >= -B && dl <= B) {
+            constexpr int ql = dl + B;
+            const float S2 = S + A[K - 1][ql];
+            nconf += finite_f(S2) ? 1 : 0;
+            upd(A, Bt, S2, std::make_integer_sequence<int, K - 1>());
+            Bt[K - 1][ql] = fminf(S2 - A[K - 1][ql], Bt[K - 1][ql]);
+        }
+    }
+    template <int... Js>
+    static __device__ __forceinline__ void upd(const float (&A)[K][Q], float (&Bt)[K][Q], float S2,
+                                               std::integer_sequence<int, Js...>)
+    {
+        constexpr int dig[sizeof...(D) + 1] = {D..., 0};
+        ((Bt[Js][dig[Js]] = fminf(S2 - A[Js][dig[Js]], Bt[Js][dig[Js]])), ...);
+    }
+};
+
+template <int Q, int K>
+__device__ __forceinline__ void q_check_unrolled(float *msg, int e0, long Bp, long b, int *err)
+{
+    float A[K][Q], Bt[K][Q];
+#pragma unroll
+    for (int j = 0; j < K; j++)
+#pragma unroll
+        for (int q = 0; q < Q; q++) {
+            A[j][q] = msg[((size_t)(e0 + j) * Q + q) * Bp + b];
+            Bt[j][q] = INFINITY;
+        }
+    int nconf = 0;
+    QEnum<Q, K, 0>::run(A, Bt, 0.0f, nconf);
+    if (nconf == 0) {
+        bool bad = false;
+#pragma unroll
+        for (int j = 0; j < K; j++) {
+            bool any = false;
+#pragma unroll
+            for (int q = 0; q < Q; q++) any |= finite_f(A[j][q]);
+            bad |= !any;
+        }
+        atomicMax(err, bad ? QERR_NO_FINITE : QERR_NO_CONFIG);
+    }
+#pragma unroll
+    for (int j = 0; j < K; j++)
+#pragma unroll
+        for (int q = 0; q < Q; q++) msg[((size_t)(e0 + j) * Q + q) * Bp + b] = Bt[j][q];
+}
+
+// grid (R, Bp/256), block 256.
+template <int Q, int KMAX>
+__global__ __launch_bounds__(256) void k_q_check_unrolled(const int *__restrict__ row_ptr, float *msg, long Bp, int batch,
+                                                          int *__restrict__ err)
+{
+    const int c = blockIdx.x;
+    const long b = (long)blockIdx.y * blockDim.x + threadIdx.x;
+    if (b >= batch) return;
+    const int e0 = row_ptr[c], k = row_ptr[c + 1] - e0;
+#define QK(KK)                                                              \
+    case KK:                                                                \
+        if constexpr (KK <= KMAX) q_check_unrolled<Q, KK>(msg, e0, Bp, b, err); \
+        break;
+    switch (k) {
+        QK(1) QK(2) QK(3) QK(4) QK(5) QK(6) QK(7) QK(8)
+        default:
+            if (threadIdx.x == 0) atomicMax(err, QERR_NO_CONFIG);  // k == 0 (k > KMAX never reaches this kernel)
+    }
+#undef QK
 }
 
 // ---------------------------------------------------------------------------
@@ -592,27 +694,66 @@ int growq(T **p, size_t *cap, size_t need)
     return 0;
 }
 
-// decoder.rs:668-692 on the host with glibc logf -- bit-identical to the oracle.
+// decoder.rs:668-692 on the host with glibc logf -- bit-identical to the oracle (and to what
+// the reference's f32::ln gives on the same platform).  One logf per symbol is the dominant
+// host cost of a large batch, so codewords are split over host threads.
 int host_into_llr(const float *pmf, int batch, int nv, int Q, long Bp, long row0, std::vector<float> &llr)
 {
-    for (int b = 0; b < batch; b++)
-        for (int v = 0; v < nv; v++) {
-            const float *p = pmf + ((size_t)b * nv + v) * Q;
-            float sum = 0.0f, mx = 0.0f;
-            bool have = false;
-            for (int q = 0; q < Q; q++) {
-                sum += p[q];
-                if (p[q] == p[q] && (!have || p[q] > mx)) {
-                    mx = p[q];
-                    have = true;
+    const size_t work = (size_t)batch * nv * Q;
+    int nthreads = 1;
+    if (work > 200000) nthreads = (int)std::min<size_t>(std::max(1u, std::thread::hardware_concurrency()), 16);
+    nthreads = std::max(1, std::min(nthreads, (batch + 63) / 64));
+    std::vector<int> bad_b(nthreads, -1), bad_v(nthreads, -1), bad_kind(nthreads, 0);
+    std::vector<float> bad_sum(nthreads, 0.0f);
+    // a thread owns 64-codeword chunks: the [batch][var][q] -> [var][q][Bp] transposition then
+    // WRITES 64 contiguous floats per (var, q) instead of one float per 4 KB stride
+    const int nchunks = (batch + 63) / 64;
+    auto worker = [&](int tid) {
+        float mx[64];
+        for (int ch = tid; ch < nchunks; ch += nthreads) {
+            const int b0 = ch * 64, nb = std::min(64, batch - b0);
+            for (int v = 0; v < nv; v++) {
+                for (int i = 0; i < nb; i++) {
+                    const int b = b0 + i;
+                    const float *p = pmf + ((size_t)b * nv + v) * Q;
+                    float sum = 0.0f, m_ = 0.0f;
+                    bool have = false;
+                    for (int q = 0; q < Q; q++) {
+                        sum += p[q];
+                        if (p[q] == p[q] && (!have || p[q] > m_)) {
+                            m_ = p[q];
+                            have = true;
+                        }
+                    }
+                    mx[i] = m_;
+                    if ((!have || !(sum < 1.0f + 0.001f) || !(sum > 1.0f - 0.001f)) &&
+                        (bad_b[tid] < 0 || b < bad_b[tid])) {
+                        bad_b[tid] = b; bad_v[tid] = v; bad_kind[tid] = have ? 2 : 1; bad_sum[tid] = sum;
+                    }
+                }
+                for (int q = 0; q < Q; q++) {
+                    float *dst = llr.data() + ((size_t)(row0 + (long)v * Q + q)) * Bp + b0;
+                    for (int i = 0; i < nb; i++) dst[i] = logf(mx[i] / pmf[((size_t)(b0 + i) * nv + v) * Q + q]);
                 }
             }
-            if (!have) return fail(SCALDPC_EPMF, "No maximum probability found (codeword %d, variable %d)", b, v);
-            if (!(sum < 1.0f + 0.001f) || !(sum > 1.0f - 0.001f))
-                return fail(SCALDPC_EPMF, "channel output of codeword %d, variable %d sums to %g, not 1 +- 1e-3", b, v,
-                            (double)sum);
-            for (int q = 0; q < Q; q++) llr[((size_t)(row0 + (long)v * Q + q)) * Bp + b] = logf(mx / p[q]);
         }
+    };
+    if (nthreads == 1) {
+        worker(0);
+    } else {
+        std::vector<std::thread> th;
+        for (int t = 0; t < nthreads; t++) th.emplace_back(worker, t);
+        for (auto &t : th) t.join();
+    }
+    int first = -1;
+    for (int t = 0; t < nthreads; t++)
+        if (bad_b[t] >= 0 && (first < 0 || bad_b[t] < bad_b[first])) first = t;
+    if (first >= 0) {
+        if (bad_kind[first] == 1)
+            return fail(SCALDPC_EPMF, "No maximum probability found (codeword %d, variable %d)", bad_b[first], bad_v[first]);
+        return fail(SCALDPC_EPMF, "channel output of codeword %d, variable %d sums to %g, not 1 +- 1e-3", bad_b[first],
+                    bad_v[first], (double)bad_sum[first]);
+    }
     return 0;
 }
 
@@ -673,9 +814,21 @@ int qary_run(scaldpc_qary *h, const float *pmf_b, const float *pmf_s, int batch,
     // a tie at batch 1024, where one codeword per lane keeps global accesses coalesced
     bool wave_mode = batch <= 256 && wave_lds <= 64 * 1024;
     if (const char *e = getenv("SCALDPC_QARY_WAVE")) wave_mode = atoi(e) != 0 && wave_lds <= 64 * 1024;
+    // small alphabets: fully unrolled register enumeration (any batch size)
+    int unrolled = 0;
+    if (!h->special && !getenv("SCALDPC_QARY_NO_UNROLL")) {
+        if (h->Q == 3 && h->maxdc <= 7) unrolled = 3;
+        if (h->Q == 5 && h->maxdc <= 5) unrolled = 5;
+    }
     for (int it = 1; it <= iters; it++) {
         if (h->E) {
-            if (wave_mode && h->special)
+            if (unrolled == 3)
+                hipLaunchKernelGGL((k_q_check_unrolled<3, 7>), dim3(h->R, Bp / 64), dim3(64), 0, s, h->d_row_ptr, h->d_msg, Bp,
+                                   batch, h->d_err);
+            else if (unrolled == 5)
+                hipLaunchKernelGGL((k_q_check_unrolled<5, 5>), dim3(h->R, Bp / 64), dim3(64), 0, s, h->d_row_ptr, h->d_msg, Bp,
+                                   batch, h->d_err);
+            else if (wave_mode && h->special)
                 hipLaunchKernelGGL(k_q_special_check_wave, dim3(h->R, batch), dim3(64), wave_lds, s, h->d_row_ptr, h->d_msg,
                                    h->B, h->BSUM, h->W, Bp, h->maxdc - 1);
             else if (wave_mode)
