@@ -429,15 +429,25 @@ __global__ __launch_bounds__(256) void k_check_tanh(Buckets bk, const int *__res
 //        hard[n], synd[m], recv[n] (received-vector mode), flag.
 // grid = batch, block = 256.
 // ---------------------------------------------------------------------------
-template <int METHOD>  // SCALDPC_BP_PRODUCT_SUM / SCALDPC_BP_MIN_SUM
+// PLANES = false: byte I/O as decode() hands it over (in: [batch][m or n], out_bits [batch][n]).
+// PLANES = true : bit-plane I/O for the Monte-Carlo entry points (in = syndrome planes
+//                 u64 [tile][m]; out_bits = hard planes u64 [tile][n], zeroed by the caller;
+//                 out_conv = conv planes u64 [tile]; out_llr = posterior [tile][var][64]).
+template <int METHOD, bool PLANES>  // METHOD: SCALDPC_BP_PRODUCT_SUM / SCALDPC_BP_MIN_SUM
 __global__ __launch_bounds__(256) void k_bp_small(const int *__restrict__ row_ptr, const int *__restrict__ col_idx,
                                                   const int *__restrict__ col_ptr, const int *__restrict__ csc_edge,
                                                   const float *__restrict__ prior, int m, int n, int E,
-                                                  const uint8_t *__restrict__ in, int kind, int max_iter, float alpha0,
-                                                  int early, uint8_t *__restrict__ out_bits,
+                                                  const void *__restrict__ in_, int kind, int max_iter, float alpha0,
+                                                  int early, void *__restrict__ out_bits_,
                                                   float *__restrict__ out_llr, int *__restrict__ out_iters,
-                                                  uint8_t *__restrict__ out_conv)
+                                                  void *__restrict__ out_conv_)
 {
+    const uint8_t *in = (const uint8_t *)in_;
+    uint8_t *out_bits = (uint8_t *)out_bits_;
+    uint8_t *out_conv = (uint8_t *)out_conv_;
+    const u64 *in_planes = (const u64 *)in_;
+    u64 *hard_planes = (u64 *)out_bits_;
+    u64 *conv_planes = (u64 *)out_conv_;
     extern __shared__ float sm[];
     float *msg = sm, *scr = sm + E;
     uint8_t *hard = (uint8_t *)(scr + E);
@@ -445,8 +455,11 @@ __global__ __launch_bounds__(256) void k_bp_small(const int *__restrict__ row_pt
     uint8_t *recv = synd + m;  // n bytes, received-vector mode only
     __shared__ int flag;
     const int b = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
+    const int pt = b >> 6, pc = b & 63;  // tile / bit of this codeword in plane I/O
 
-    if (kind == SCALDPC_IN_SYNDROME) {
+    if (PLANES) {
+        for (int r = tid; r < m; r += nt) synd[r] = (uint8_t)((in_planes[(size_t)pt * m + r] >> pc) & 1);
+    } else if (kind == SCALDPC_IN_SYNDROME) {
         for (int r = tid; r < m; r += nt) synd[r] = in[(size_t)b * m + r] & 1;
     } else {
         for (int v = tid; v < n; v += nt) recv[v] = in[(size_t)b * n + v] & 1;
@@ -531,7 +544,7 @@ __global__ __launch_bounds__(256) void k_bp_small(const int *__restrict__ row_pt
             }
             if (outs) {
                 hard[v] = temp <= 0.0f;
-                if (out_llr) out_llr[(size_t)b * n + v] = temp;
+                if (out_llr) out_llr[PLANES ? ((size_t)pt * n + v) * TW + pc : (size_t)b * n + v] = temp;
             }
         }
         if (tid == 0) flag = 0;
@@ -550,6 +563,15 @@ __global__ __launch_bounds__(256) void k_bp_small(const int *__restrict__ row_pt
                 break;
             }
         }
+    }
+    if (PLANES) {
+        for (int v = tid; v < n; v += nt)
+            if (hard[v]) atomicOr(hard_planes + (size_t)pt * n + v, 1ull << pc);
+        if (tid == 0) {
+            out_iters[b] = it_done;
+            if (conv) atomicOr(conv_planes + pt, 1ull << pc);
+        }
+        return;
     }
     for (int v = tid; v < n; v += nt)
         out_bits[(size_t)b * n + v] = hard[v] ^ (kind == SCALDPC_IN_RECEIVED ? recv[v] : (uint8_t)0);
@@ -1122,6 +1144,26 @@ int run_core(scaldpc_bp *h, int batch, int T, int G, int max_iter, int method, f
     h->last_group = std::min(G, T);
     h->stat_deferred = 0;
 
+    // small graph: the LDS-resident single-launch decoder, plane I/O (Monte-Carlo entry points)
+    {
+        const size_t small_lds = (size_t)2 * h->E * sizeof(float) + (size_t)2 * h->n + h->m + 64;
+        const char *force = getenv("SCALDPC_PATH");
+        if (small_lds <= 60 * 1024 && h->E > 0 && !(force && !strcmp(force, "stream"))) {
+#define SMALL_PLANES(M)                                                                                              \
+    hipLaunchKernelGGL((k_bp_small<M, true>), dim3(batch), dim3(256), small_lds, s, h->d_row_ptr, h->d_col_idx,         \
+                       h->d_col_ptr, h->d_csc_edge, h->d_prior, h->m, h->n, (int)h->E, (const void *)h->d_synd,         \
+                       SCALDPC_IN_SYNDROME, max_iter, alpha, early ? 1 : 0, (void *)h->d_hard,                          \
+                       want_post ? h->d_post : (float *)nullptr, h->d_iters, (void *)h->d_conv)
+            if (method == SCALDPC_BP_MIN_SUM)
+                SMALL_PLANES(SCALDPC_BP_MIN_SUM);
+            else
+                SMALL_PLANES(SCALDPC_BP_PRODUCT_SUM);
+#undef SMALL_PLANES
+            LAUNCH_CHECK();
+            return 0;
+        }
+    }
+
     int defer_after = 0;
     if (early) {
         defer_after = 8;
@@ -1401,7 +1443,7 @@ int scaldpc_bp_decode_batch(scaldpc_bp *h, const uint8_t *in, int32_t input_kind
             dconv = out_conv ? h->d_out_conv : nullptr;
         }
 #define SMALL_LAUNCH(M)                                                                                            \
-    hipLaunchKernelGGL(k_bp_small<M>, dim3(batch), dim3(256), small_lds, s, h->d_row_ptr, h->d_col_idx, h->d_col_ptr, \
+    hipLaunchKernelGGL((k_bp_small<M, false>), dim3(batch), dim3(256), small_lds, s, h->d_row_ptr, h->d_col_idx, h->d_col_ptr, \
                        h->d_csc_edge, h->d_prior, h->m, h->n, (int)h->E, din, input_kind, max_iter, alpha,          \
                        early ? 1 : 0, dbits, dllr, diters, dconv)
         if (method == SCALDPC_BP_MIN_SUM)
