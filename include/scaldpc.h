@@ -35,8 +35,11 @@
  * pointers and are staged through device memory by the call.  With
  * SCALDPC_F_DEVICE_IO they are device pointers (e.g. torch tensors' data_ptr())
  * and nothing crosses PCIe.  `stream` is a hipStream_t passed as void* (NULL =
- * the handle's own stream); the call returns after the stream work is complete
- * unless SCALDPC_F_ASYNC is set (device I/O only).
+ * the handle's own non-blocking stream); the call returns after the stream work is
+ * complete unless SCALDPC_F_ASYNC is set (device I/O only).  With device pointers the
+ * caller owns the ordering: pass the stream the inputs were produced on (or
+ * synchronise first), and do not touch the handle's priors or buffers while an
+ * SCALDPC_F_ASYNC call is still in flight.
  */
 #ifndef SCALDPC_H
 #define SCALDPC_H

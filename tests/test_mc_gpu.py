@@ -70,6 +70,7 @@ def test_mc_device_outputs():
     host = dec.mc_hqc_run(200, omega=5, eps=0.04, seed=9)
     d_s = torch.zeros(200, dtype=torch.uint8, device="cuda")
     d_i = torch.zeros(200, dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()  # stream = NULL below means the handle's own stream: order it after torch's fills
     lib.check(dec._lib.scaldpc_mc_hqc_run(dec._h, 5, 0.04, 0, 200, 9, 40, lib.BP_MIN_SUM, 1.0,
                                           lib.F_EARLY_EXIT | lib.F_DEVICE_IO, None, C.c_void_p(d_s.data_ptr()),
                                           C.c_void_p(d_i.data_ptr()), None, None))
