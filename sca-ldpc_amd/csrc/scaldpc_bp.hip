@@ -1083,8 +1083,8 @@ struct TileState {
 };
 
 // All iterations of the tile group [g0, g0+g) of `st`.  With defer_after > 0 the group
-// stops after that many iterations when at most half of its codewords are still running
-// and reports *deferred = true: those codewords go to the compact pass.
+// stops at the first poll point from that iteration on at which at most half of its
+// codewords are still running, and reports *deferred = true: those go to the compact pass.
 int iterate_group(scaldpc_bp *h, const TileState &st, int g0, int g, int max_iter, int method, float alpha, bool early,
                   int defer_after, hipStream_t s, bool *deferred)
 {
@@ -1114,13 +1114,15 @@ int iterate_group(scaldpc_bp *h, const TileState &st, int g0, int g, int max_ite
                                h->d_remaining + it);
             LAUNCH_CHECK();
         }
-        const bool defer_point = defer_after > 0 && it == defer_after;
-        if (early && !last && (it % poll_every == 0 || it == 1 || defer_point)) {
+        const bool poll = it % poll_every == 0 || it == 1 || it == defer_after;
+        if (early && !last && poll) {
             SC_HIP(hipMemcpyAsync(h->h_remaining + it, h->d_remaining + it, sizeof(int), hipMemcpyDeviceToHost, s));
             SC_HIP(hipStreamSynchronize(s));
             const int rem = h->h_remaining[it];
             if (rem == 0) break;
-            if (defer_point && 2 * rem <= g * TW) {
+            // from `defer_after` on, any poll point may hand the stragglers over, provided the
+            // restart (it iterations redone) is cheap next to what is still ahead
+            if (defer_after > 0 && it >= defer_after && 2 * it < max_iter && 2 * rem <= g * TW) {
                 *deferred = true;
                 break;
             }
@@ -1166,7 +1168,7 @@ int run_core(scaldpc_bp *h, int batch, int T, int G, int max_iter, int method, f
 
     int defer_after = 0;
     if (early) {
-        defer_after = 8;
+        defer_after = 4;  // measured on the config-5 sweep: 4-5 best (177k trials/s), 8: 156k, 12: 136k
         if (const char *e = getenv("SCALDPC_COMPACT_AFTER")) defer_after = atoi(e);
         if (max_iter <= 2 * defer_after) defer_after = 0;  // nothing to gain
     }
