@@ -812,7 +812,9 @@ int qary_run(scaldpc_qary *h, const float *pmf_b, const float *pmf_s, int batch,
                                 : (size_t)h->maxdc * h->Q * 4 * 65 + (size_t)h->maxdc * h->Q + h->maxdc + 16;
     // measured: wave mode 0.69 vs 3.2 ms at batch 64 (config-4 decoder), 24 vs 70 ms (Kyber SW6);
     // a tie at batch 1024, where one codeword per lane keeps global accesses coalesced
-    bool wave_mode = batch <= 256 && wave_lds <= 64 * 1024;
+    // the special decoder (15625 assignments per check at the Kyber shape) prefers wave mode at
+    // every batch size measured (93 vs 153 ms at batch 256)
+    bool wave_mode = (batch <= 256 || h->special) && wave_lds <= 64 * 1024;
     if (const char *e = getenv("SCALDPC_QARY_WAVE")) wave_mode = atoi(e) != 0 && wave_lds <= 64 * 1024;
     // small alphabets: fully unrolled register enumeration (any batch size)
     int unrolled = 0;
