@@ -137,6 +137,8 @@ class BpDecoder:
 
     def decode(self, input_vector):
         """One decode, reference semantics (early exit at H e == s).  Returns int array [n]."""
+        if hasattr(input_vector, "toarray"):  # scipy.sparse vector, which the package accepts too
+            input_vector = input_vector.toarray()
         v = np.asarray(input_vector)
         if v.ndim != 1:
             v = v.reshape(-1)
@@ -245,6 +247,13 @@ class BpDecoder:
         if getattr(self, "_h", None):
             self._lib.scaldpc_bp_destroy(self._h)
             self._h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+        return False
 
     def __del__(self):
         try:

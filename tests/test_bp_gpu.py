@@ -333,3 +333,16 @@ def test_large_batch(oracle, monkeypatch):
         ref = oracle.bp_decode_batch(H, probs, synd[sl], 0, 12, "min_sum", dtype="f32", threads=4)
         compare({k: v[sl] for k, v in got.items()}, ref, "min_sum")
     dec.close()
+
+
+def test_sparse_vector_input_and_context_manager():
+    import scipy.sparse as sp
+
+    g = S.codes.rep_code_graph(13)
+    s = np.zeros(12, dtype=int)
+    s[3] = s[4] = 1
+    with bp.bp_decoder(sp.csr_matrix(g.to_dense()), error_rate=0.05, max_iter=13) as dec:
+        a = dec.decode(s)
+        b = dec.decode(sp.csr_matrix(s))
+        assert np.array_equal(a, b) and a[4] == 1 and a.sum() == 1 and dec.converge == 1
+    assert dec._h is None
