@@ -250,10 +250,13 @@ __global__ __launch_bounds__(256) void k_init_msg(const int *__restrict__ col_id
 // (reading edge k before overwriting edge k keeps that legal in place).
 // wave = (row, tile), lane = codeword.  grid (ceil(m/4), G), block 256 = 4 rows.
 // ---------------------------------------------------------------------------
-template <bool WIDE>
+// FIRST: iteration 1 takes its inputs straight from the priors (v2c = prior of the edge's
+// column by definition), so the message array needs no initialisation pass and is not read.
+template <bool WIDE, bool FIRST>
 __global__ __launch_bounds__(256) void k_check_minsum(const int *__restrict__ row_ptr, float *msg,
                                                       const u64 *__restrict__ synd, const u64 *__restrict__ done,
-                                                      int skip_done, int m, long E, float alpha)
+                                                      int skip_done, int m, long E, float alpha,
+                                                      const int *__restrict__ col_idx, const float *__restrict__ prior)
 {
     const int lane = threadIdx.x & 63;
     int r = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -270,7 +273,7 @@ __global__ __launch_bounds__(256) void k_check_minsum(const int *__restrict__ ro
     u64 neg = 0;
 #pragma unroll 8
     for (int k = 0; k < deg; k++) {
-        const float x = p[(size_t)k * TW];
+        const float x = FIRST ? prior[rfl(col_idx[e0 + k])] : p[(size_t)k * TW];
         const float a = fabsf(x);
         const unsigned n_ = x <= 0.0f;
         par ^= n_;
@@ -283,7 +286,8 @@ __global__ __launch_bounds__(256) void k_check_minsum(const int *__restrict__ ro
     const float nalpha = -alpha;
 #pragma unroll 8
     for (int k = 0; k < deg; k++) {
-        const unsigned b = WIDE ? (unsigned)(p[(size_t)k * TW] <= 0.0f) : ((unsigned)(neg >> k) & 1u);
+        const unsigned b = WIDE ? (unsigned)((FIRST ? prior[rfl(col_idx[e0 + k])] : p[(size_t)k * TW]) <= 0.0f)
+                                : ((unsigned)(neg >> k) & 1u);
         p[(size_t)k * TW] = ((k == ix) ? m2 : m1) * ((par ^ b) ? nalpha : alpha);
     }
 }
@@ -1031,18 +1035,24 @@ int ensure_workspace(scaldpc_bp *h, int T, int G, bool want_post, int max_iter)
 
 #define LAUNCH_CHECK() SC_HIP(hipGetLastError())
 
+// min-sum needs no message initialisation pass: its first check update reads the priors
+bool fused_init(const scaldpc_bp *h, int method) { return method == SCALDPC_BP_MIN_SUM && h->E > 0; }
+
 int launch_check(scaldpc_bp *h, int method, float alpha, int G, const u64 *synd_g, const u64 *done_g, int skip_done,
-                 hipStream_t s)
+                 hipStream_t s, bool first = false)
 {
     if (h->E == 0) return 0;
     if (method == SCALDPC_BP_MIN_SUM) {
         dim3 grid((h->m + 3) / 4, G);
-        if (h->max_row_deg <= ROW_CAP)
-            hipLaunchKernelGGL(k_check_minsum<false>, grid, dim3(256), 0, s, h->d_row_ptr, h->d_msg, synd_g, done_g,
-                               skip_done, h->m, h->E, alpha);
-        else
-            hipLaunchKernelGGL(k_check_minsum<true>, grid, dim3(256), 0, s, h->d_row_ptr, h->d_msg, synd_g, done_g,
-                               skip_done, h->m, h->E, alpha);
+#define MS_LAUNCH(W, F)                                                                                              \
+    hipLaunchKernelGGL((k_check_minsum<W, F>), grid, dim3(256), 0, s, h->d_row_ptr, h->d_msg, synd_g, done_g, skip_done, \
+                       h->m, h->E, alpha, h->d_col_idx, h->d_prior)
+        if (h->max_row_deg <= ROW_CAP) {
+            if (first) MS_LAUNCH(false, true); else MS_LAUNCH(false, false);
+        } else {
+            if (first) MS_LAUNCH(true, true); else MS_LAUNCH(true, false);
+        }
+#undef MS_LAUNCH
     } else {
         dim3 grid(h->row_bk.blk[h->row_bk.nb], G);
         if (h->max_row_deg <= 16)
@@ -1104,7 +1114,8 @@ int iterate_group(scaldpc_bp *h, const TileState &st, int g0, int g, int max_ite
     int *iters_g = st.iters + (size_t)g0 * TW;
     float *post_g = st.post ? st.post + (size_t)g0 * h->n * TW : nullptr;
     *deferred = false;
-    if (h->E) {
+    const bool fused = fused_init(h, method);
+    if (h->E && !fused) {
         hipLaunchKernelGGL(k_init_msg, dim3((unsigned)((h->E + 3) / 4), g), dim3(256), 0, s, h->d_col_idx, h->d_prior,
                            h->d_msg, h->E);
         LAUNCH_CHECK();
@@ -1112,7 +1123,7 @@ int iterate_group(scaldpc_bp *h, const TileState &st, int g0, int g, int max_ite
     if (early) SC_HIP(hipMemsetAsync(h->d_remaining, 0, sizeof(int) * ((size_t)max_iter + 2), s));
     for (int it = 1; it <= max_iter; it++) {
         const bool last = it == max_iter;
-        SC_TRY(launch_check(h, method, alpha_for(alpha, it), g, synd_g, done_g, skip, s));
+        SC_TRY(launch_check(h, method, alpha_for(alpha, it), g, synd_g, done_g, skip, s, fused && it == 1));
         SC_TRY(launch_var(h, g, post_g, hard_g, done_g, skip, (early || last) ? 1 : 0, s));
         if (early || last) {
             hipLaunchKernelGGL(k_parity<true>, dim3((h->m + 4 * ROWS_PER_WAVE - 1) / (4 * ROWS_PER_WAVE), g), dim3(256), 0, s, h->d_row_ptr, h->d_col_idx,
