@@ -668,9 +668,12 @@ __global__ __launch_bounds__(256) void k_var(Buckets bk, const int *__restrict__
     while (b + 1 < bk.nb && (int)blockIdx.x >= bk.blk[b + 1]) b++;
     const int slot = ((int)blockIdx.x - bk.blk[b]) * 4 + (threadIdx.x >> 6);
     if (slot >= bk.cnt[b]) return;
-    const int v = rfl(list[bk.off[b] + slot]);
-    const int cb = rfl(col_ptr[v]);
-    const int d = rfl(col_ptr[v + 1]) - cb;
+    // one 16-byte descriptor per column in launch order: {column, start in the re-laid edge
+    // list, degree}; `csc_edge` here is the edge list laid out in that same order
+    const int4 md = ((const int4 *)list)[bk.off[b] + slot];
+    const int v = rfl(md.x);
+    const int cb = rfl(md.y);
+    const int d = rfl(md.z);
     float *mt = msg + (size_t)tl * E * TW + lane;
     const int *ce = csc_edge + cb;
     const float pr = prior[v];
@@ -902,6 +905,7 @@ struct scaldpc_bp {
     // device graph
     int *d_row_ptr = nullptr, *d_col_idx = nullptr, *d_col_ptr = nullptr, *d_csc_edge = nullptr;
     int *d_var_list = nullptr, *d_row_list = nullptr;
+    int *d_var_meta = nullptr, *d_csc_list = nullptr;  // k_var: packed column descriptors + edge lists in launch order
     Buckets var_bk{}, row_bk{};
     bool need_scratch = false;
     // priors
@@ -1074,7 +1078,7 @@ int launch_var(scaldpc_bp *h, int G, float *post_g, u64 *hard_g, const u64 *done
 {
     dim3 grid(h->var_bk.blk[h->var_bk.nb], G);
 #define VAR_LAUNCH(CAP)                                                                                             \
-    hipLaunchKernelGGL(k_var<CAP>, grid, dim3(256), 0, s, h->var_bk, h->d_var_list, h->d_col_ptr, h->d_csc_edge,      \
+    hipLaunchKernelGGL(k_var<CAP>, grid, dim3(256), 0, s, h->var_bk, h->d_var_meta, h->d_col_ptr, h->d_csc_list,      \
                        h->d_prior, h->d_msg, h->d_scratch, post_g, hard_g, done_g, skip_done, h->n, h->E, write_out)
     if (h->max_col_deg <= 16)
         VAR_LAUNCH(16);
@@ -1359,6 +1363,20 @@ int scaldpc_bp_create(int32_t m, int32_t n, int64_t nnz, const int32_t *row_ptr,
     if (!rc) rc = up(&h->d_col_ptr, col_ptr.data(), (size_t)n + 1);
     if (!rc) rc = up(&h->d_csc_edge, csc_edge.data(), (size_t)nnz);
     if (!rc) rc = up(&h->d_var_list, hv.list.data(), hv.list.size());
+    {
+        std::vector<int> meta(4 * hv.list.size() + 4, 0), relaid((size_t)nnz + 1, 0);
+        int pos = 0;
+        for (size_t i = 0; i < hv.list.size(); i++) {
+            const int v = hv.list[i], d = col_ptr[v + 1] - col_ptr[v];
+            meta[4 * i + 0] = v;
+            meta[4 * i + 1] = pos;
+            meta[4 * i + 2] = d;
+            for (int k = 0; k < d; k++) relaid[pos + k] = csc_edge[(size_t)col_ptr[v] + k];
+            pos += d;
+        }
+        if (!rc) rc = up(&h->d_var_meta, meta.data(), meta.size());
+        if (!rc) rc = up(&h->d_csc_list, relaid.data(), relaid.size());
+    }
     if (!rc) rc = up(&h->d_row_list, hr.list.data(), hr.list.size());
     if (!rc) rc = dev_alloc(&h->d_prior, (size_t)n);
     if (!rc && hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking) != hipSuccess)
@@ -1747,6 +1765,7 @@ void scaldpc_bp_destroy(scaldpc_bp *h)
     if (!h) return;
     dev_free(h->d_row_ptr); dev_free(h->d_col_idx); dev_free(h->d_col_ptr); dev_free(h->d_csc_edge);
     dev_free(h->d_var_list); dev_free(h->d_row_list); dev_free(h->d_prior);
+    dev_free(h->d_var_meta); dev_free(h->d_csc_list);
     dev_free(h->d_msg); dev_free(h->d_scratch); dev_free(h->d_post);
     dev_free(h->d_synd); dev_free(h->d_recv); dev_free(h->d_hard); dev_free(h->d_done);
     dev_free(h->d_conv); dev_free(h->d_unsat); dev_free(h->d_iters); dev_free(h->d_remaining);
