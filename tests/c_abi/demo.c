@@ -1,0 +1,63 @@
+/* Plain-C client of libscaldpc (no Python, no torch): builds the repetition-code decoder of
+ * the reference's "official example" (main.py:265-276), decodes a batch of syndromes with
+ * early exit, and a tiny q-ary instance (decoder.rs:771-799).  Used by tests/test_c_abi_gpu.py.
+ * build: gcc -O2 -I include tests/c_abi/demo.c -o demo -L sca-ldpc_amd -lscaldpc -Wl,-rpath,... */
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include "scaldpc.h"
+
+#define CHECK(x) do { int rc_ = (x); if (rc_) { fprintf(stderr, "%s -> %d: %s\n", #x, rc_, scaldpc_last_error()); return 1; } } while (0)
+
+int main(void)
+{
+    /* rep_code(13): row i = {i, i+1} */
+    enum { N = 13, M = 12, BATCH = 70 };
+    int32_t row_ptr[M + 1], col_idx[2 * M];
+    for (int i = 0; i <= M; i++) row_ptr[i] = 2 * i;
+    for (int i = 0; i < M; i++) { col_idx[2 * i] = i; col_idx[2 * i + 1] = i + 1; }
+    scaldpc_bp *h = NULL;
+    CHECK(scaldpc_bp_create(M, N, 2 * M, row_ptr, col_idx, &h));
+    double probs[N];
+    for (int j = 0; j < N; j++) probs[j] = 0.05;
+    CHECK(scaldpc_bp_set_channel_probs(h, probs));
+    /* codeword b carries a single error at position b % 13 */
+    uint8_t synd[BATCH][M], bits[BATCH][N], conv[BATCH];
+    int32_t iters[BATCH];
+    memset(synd, 0, sizeof synd);
+    for (int b = 0; b < BATCH; b++) {
+        int e = b % N;
+        if (e > 0) synd[b][e - 1] ^= 1;
+        if (e < M) synd[b][e] ^= 1;
+    }
+    CHECK(scaldpc_bp_decode_batch(h, &synd[0][0], SCALDPC_IN_SYNDROME, BATCH, N, SCALDPC_BP_PRODUCT_SUM, 1.0f,
+                                  SCALDPC_F_EARLY_EXIT, NULL, &bits[0][0], NULL, iters, conv));
+    int ok = 0;
+    for (int b = 0; b < BATCH; b++) {
+        int good = conv[b] == 1;
+        for (int j = 0; j < N; j++) good &= bits[b][j] == (j == b % N);
+        ok += good;
+    }
+    printf("bp: %d/%d single errors corrected, iters[0]=%d\n", ok, BATCH, iters[0]);
+    /* bad arguments come back as codes, not crashes */
+    int rc = scaldpc_bp_decode_batch(h, &synd[0][0], 7, BATCH, N, SCALDPC_BP_MIN_SUM, 1.0f, 0, NULL, &bits[0][0], NULL, NULL, NULL);
+    printf("bad input kind -> %d (%s)\n", rc, scaldpc_last_error());
+    scaldpc_bp_destroy(h);
+
+    /* q-ary: decoder.rs:771-799, one bad symbol, Q = 15 */
+    const int8_t H[3][6] = {{1, 1, 1, 1, 0, 0}, {0, 0, 1, 1, 0, 1}, {1, 0, 0, 1, 1, 0}};
+    scaldpc_qary *q = NULL;
+    CHECK(scaldpc_qary_create(3, 6, 7, &H[0][0], 10, &q));
+    float pmf[6][15];
+    memset(pmf, 0, sizeof pmf);
+    for (int v = 0; v < 6; v++) pmf[v][7] = 1.0f;
+    pmf[1][7] = 0.1f;
+    pmf[1][14] = 0.9f;
+    int8_t out[6];
+    CHECK(scaldpc_qary_min_sum_batch(q, &pmf[0][0], 1, 0, NULL, out));
+    int zeros = 1;
+    for (int v = 0; v < 6; v++) zeros &= out[v] == 0;
+    printf("qary: all-zero decoding %s\n", zeros ? "yes" : "no");
+    scaldpc_qary_destroy(q);
+    return (ok == BATCH && rc == SCALDPC_EINVAL && zeros) ? 0 : 2;
+}
