@@ -240,6 +240,12 @@ class BpDecoder:
         _lib.check(self._lib.scaldpc_bp_last_compacted(self._h, C.byref(c)))
         return int(c.value)
 
+    def last_row_parallel(self):
+        """Codewords the last call decoded with the row-parallel (lane = edge) kernels."""
+        c = C.c_int64()
+        _lib.check(self._lib.scaldpc_bp_last_row_parallel(self._h, C.byref(c)))
+        return int(c.value)
+
     def set_tile_group(self, tiles):
         _lib.check(self._lib.scaldpc_bp_set_tile_group(self._h, int(tiles)))
 

@@ -701,6 +701,152 @@ __global__ __launch_bounds__(256) void k_var(Buckets bk, const int *__restrict__
 }
 
 // ---------------------------------------------------------------------------
+// Row-parallel ("edge-lane") kernels for a HANDFUL of codewords on a graph too large for
+// LDS: the single `decode()` of the attack loop (hqc.py:708 -- one codeword, n ~ 20 000,
+// up to 100 iterations) and the few stragglers the compact pass re-decodes.  A 64-codeword
+// tile would stream 64 lanes of messages to use one; here the layout is per codeword
+//     emsg : float [codeword][edge]          (CSR order: a row's messages are contiguous)
+// and a wave owns one (row, codeword): LANE = EDGE of the row.  The row's messages are
+// one coalesced load, reductions over the row are wave primitives (ballot / popcount for
+// the sign parity, xor-shuffle butterflies for the two minima), the tanh rule's exclusive
+// forward/backward products walk the row with v_readlane broadcasts IN THE REFERENCE'S
+// ORDER, so every value is bit-identical to the tile kernels'.  State (syndrome, hard
+// decisions, done / unsat masks, posterior) stays in the tile formats: the codewords are
+// bits 0..nb-1 of one tile, so k_parity / k_finalize and all I/O kernels are shared.
+// Rows of degree <= 64 only (the host falls back to the tile path otherwise).
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ float wave_min_f(float v)
+{
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v = fminf(v, __shfl_xor(v, off));
+    return v;
+}
+__device__ __forceinline__ float readlane_f(float v, int l)
+{
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));
+}
+
+// tanh rule only (min-sum's first check pass reads the priors).  grid (ceil(E/256), nb).
+__global__ __launch_bounds__(256) void k_el_init(const int *__restrict__ col_idx, const float *__restrict__ prior,
+                                                 float *__restrict__ emsg, long E)
+{
+    const long e = (long)blockIdx.x * 256 + threadIdx.x;
+    if (e < E) emsg[(size_t)blockIdx.y * E + e] = prior[col_idx[e]];
+}
+
+// METHOD as in the C ABI; FIRST: inputs are the priors (min-sum, iteration 1).
+// grid (ceil(m/4), nb), block 256 = 4 rows of codeword blockIdx.y.
+template <int METHOD, bool FIRST>
+__global__ __launch_bounds__(256) void k_el_check(const int *__restrict__ row_ptr, const int *__restrict__ col_idx,
+                                                  const float *__restrict__ prior, float *emsg,
+                                                  const u64 *__restrict__ synd, const u64 *__restrict__ done,
+                                                  int skip_done, int m, long E, float alpha)
+{
+    const int lane = threadIdx.x & 63;
+    int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= m) return;
+    r = rfl(r);
+    const int c = blockIdx.y;
+    if (skip_done && ((done[0] >> c) & 1)) return;  // frozen codeword
+    const int e0 = rfl(row_ptr[r]);
+    const int deg = rfl(row_ptr[r + 1]) - e0;
+    if (deg == 0) return;
+    const bool act = lane < deg;
+    float *p = emsg + (size_t)c * E + e0 + lane;
+    float x = 0.0f;
+    if (act) x = FIRST ? prior[col_idx[e0 + lane]] : *p;
+    const unsigned sbit = (unsigned)(synd[r] >> c) & 1u;
+    if (METHOD == SCALDPC_BP_MIN_SUM) {
+        // the sequential form starts its running minima at FLT_MAX: |x| = inf never wins
+        const float a = act ? fminf(fabsf(x), FLT_MAX) : FLT_MAX;
+        const bool ng = act && x <= 0.0f;
+        const unsigned par = sbit ^ ((unsigned)__popcll(__ballot(ng)) & 1u);
+        const float m1 = wave_min_f(a);
+        const int ix = __ffsll((long long)__ballot(act && a == m1)) - 1;  // first arg-min
+        const float m2 = wave_min_f(lane == ix ? FLT_MAX : a);
+        if (act) *p = ((lane == ix) ? m2 : m1) * ((par ^ (unsigned)ng) ? -alpha : alpha);
+    } else {
+        const unsigned xb = act ? __float_as_uint(x) : 0u;
+        const float u = act ? tanh_compl(fabsf(x)) : 0.0f;
+        const unsigned par = sbit ^ ((unsigned)__popcll(__ballot((xb >> 31) != 0u)) & 1u);
+        float pre = 0.0f, suf = 0.0f;  // exclusive forward / backward complements of this lane's edge
+#pragma unroll 4
+        for (int t = 0; t < deg; t++) {
+            const float nv = compl_step(pre, readlane_f(u, t));
+            pre = (t < lane) ? nv : pre;
+        }
+#pragma unroll 4
+        for (int t = deg - 1; t >= 0; t--) {
+            const float nv = compl_step(suf, readlane_f(u, t));
+            suf = (t > lane) ? nv : suf;
+        }
+        const float Lm = llr_from_compl(compl_step(pre, suf));
+        const unsigned sg = ((par << 31) ^ xb) & 0x80000000u;  // parity of the OTHER inputs
+        if (act) *p = __uint_as_float(__float_as_uint(Lm) ^ sg);
+    }
+}
+
+// Variable nodes, lane = EDGE OF A COLUMN.  The host packs whole columns (in degree order) into
+// waves of 64 lane slots (a column of degree d takes max(d, 1) neighbouring slots); a slot is
+// {edge id or -1, first lane of the column's segment | position << 6 | degree << 13 | valid << 20},
+// a wave additionally knows {its largest degree, the index of its first column in `cols`}.
+// All of a wave's messages arrive with ONE gather (a thread walking its column alone pays a
+// dependent cross-XCD load per edge: 25 us per pass), then the exclusive prefix / suffix sums
+// run over the segment with per-lane shuffles in the reference's sequential order:
+//   pre_k = ((prior + m_0) + ... + m_{k-1}),  suf_k = ((0 + m_{d-1}) + ... + m_{k+1}),  out_k = pre_k + suf_k
+// exactly the values var_col produces.  The segment's first lane owns the column (prior in,
+// posterior and hard decision out); the codewords of one tile word are set / cleared with
+// atomics (each launch row owns one bit).
+// grid (waves padded to a multiple of 8 over 4, nb), block 256 = 4 packed waves.
+__global__ __launch_bounds__(256) void k_el_var(const int2 *__restrict__ slots, const int2 *__restrict__ wave_info,
+                                                const int *__restrict__ cols, int nwaves,
+                                                const float *__restrict__ prior, float *emsg,
+                                                float *__restrict__ post, u64 *__restrict__ hard,
+                                                const u64 *__restrict__ done, int skip_done, long E, int write_out)
+{
+    const int lane = threadIdx.x & 63;
+    int w = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (w >= nwaves) return;
+    w = rfl(w);
+    const int c = blockIdx.y;
+    if (skip_done && ((done[0] >> c) & 1)) return;  // frozen codeword
+    const int2 sl = slots[(size_t)w * 64 + lane];
+    const int e = sl.x, start = sl.y & 63, pos = (sl.y >> 6) & 127, deg = (sl.y >> 13) & 127;
+    const bool head = ((sl.y >> 20) & 1) && pos == 0;  // first lane of a column's segment
+    const int2 wi = wave_info[w];
+    const int dmax = rfl(wi.x);
+    float *mt = emsg + (size_t)c * E;
+    const float mk = e >= 0 ? mt[e] : 0.0f;
+    // the column id of a segment = (number of heads before it)-th column of this wave
+    const u64 heads = __ballot(head);
+    int v = 0;
+    float pr = 0.0f;
+    if (head) {
+        v = cols[rfl(wi.y) + __popcll(heads & ((1ull << lane) - 1))];
+        pr = prior[v];
+    }
+    pr = __shfl(pr, start);
+    float pre = pr, tot = pr, suf = 0.0f;
+    for (int t = 0; t < dmax; t++) {
+        const float val = __shfl(mk, (start + t) & 63);
+        pre = (t < pos) ? pre + val : pre;
+        tot = (t < deg) ? tot + val : tot;
+    }
+    for (int t = dmax - 1; t >= 0; t--) {
+        const float val = __shfl(mk, (start + t) & 63);
+        suf = (t > pos && t < deg) ? suf + val : suf;
+    }
+    if (e >= 0) mt[e] = pre + suf;
+    if (write_out && head) {
+        if (tot <= 0.0f)
+            atomicOr(hard + v, 1ull << c);
+        else
+            atomicAnd(hard + v, ~(1ull << c));
+        if (post) post[(size_t)v * TW + c] = tot;
+    }
+}
+
+// ---------------------------------------------------------------------------
 // K6  Monte-Carlo helpers: per-trial noise sampling, syndrome and success compare on the
 // device (the reference does these per position in Python: simulate/decode.py:36-40,
 // 166-168, 173-175; simulate/hqc.py:684-705, 742-749).
@@ -939,13 +1085,58 @@ struct scaldpc_bp {
     float *d_post2 = nullptr;
     size_t cap_post2 = 0, cap_slot_of = 0;
     long stat_deferred = 0;  // codewords re-decoded by the compact pass in the last call
+    // row-parallel path (a handful of codewords): per-codeword message / prefix arrays [codeword][edge]
+    float *d_emsg = nullptr;
+    size_t cap_el = 0;
+    int *d_el_slots = nullptr, *d_el_winfo = nullptr;  // k_el_var: columns packed into waves of 64 lane slots
+    int el_waves = 0;
+    int *d_graph = nullptr;  // ONE allocation behind every graph array above and d_prior (views into it)
+    int stat_el = 0;  // codewords the row-parallel kernels decoded in the last call
     int identity_from = -1;  // n - m if the last m columns of H are I_m (H = [Hin | I]), else -1
     hipStream_t own_stream = nullptr;
+    int device = 0;  // the device the handle (and its stream) was created on
     int last_group = 0;  // tiles of the last decoded group (for scaldpc_bp_time_kernels)
     std::mutex mu;
 };
 
 namespace {
+
+// Streams of destroyed handles are parked per device and handed to the next handle created
+// there (creating and destroying a stream per decoder costs more than a single decode).
+struct StreamPool {
+    std::mutex mu;
+    std::vector<std::pair<int, hipStream_t>> idle;
+};
+StreamPool &stream_pool()
+{
+    static StreamPool *p = new StreamPool();  // never destroyed: the HIP runtime may be gone at exit
+    return *p;
+}
+int stream_acquire(hipStream_t *out, int *device)
+{
+    int dev = 0;
+    SC_HIP(hipGetDevice(&dev));
+    *device = dev;
+    {
+        StreamPool &sp = stream_pool();
+        std::lock_guard<std::mutex> lk(sp.mu);
+        for (size_t i = 0; i < sp.idle.size(); i++)
+            if (sp.idle[i].first == dev) {
+                *out = sp.idle[i].second;
+                sp.idle.erase(sp.idle.begin() + i);
+                return 0;
+            }
+    }
+    SC_HIP(hipStreamCreateWithFlags(out, hipStreamNonBlocking));
+    return 0;
+}
+void stream_release(hipStream_t s, int dev)
+{
+    StreamPool &sp = stream_pool();
+    std::lock_guard<std::mutex> lk(sp.mu);
+    // the handle synchronised its stream before every return, nothing is in flight
+    if (sp.idle.size() < 64) sp.idle.emplace_back(dev, s); else (void)hipStreamDestroy(s);
+}
 
 // bucket b holds nodes with bounds[b-1] < deg <= bounds[b]; beyond the last bound -> generic (maxd 0)
 void build_buckets(const std::vector<int> &deg, const int *bounds, int nb, bool keep_isolated, HostBuckets &out)
@@ -1018,13 +1209,7 @@ int ensure_workspace(scaldpc_bp *h, int T, int G, bool want_post, int max_iter)
         SC_TRY(dev_alloc(&h->d_post, (size_t)h->cap_tiles * h->n * TW));
         h->post_alloc = true;
     }
-    if (G > h->cap_group) {
-        dev_free(h->d_msg); dev_free(h->d_scratch);
-        h->cap_group = 0;
-        SC_TRY(dev_alloc(&h->d_msg, (size_t)G * h->E * TW));
-        if (h->need_scratch) SC_TRY(dev_alloc(&h->d_scratch, (size_t)G * h->E * TW));
-        h->cap_group = G;
-    }
+    (void)G;  // the message arrays are allocated by the path that uses them (ensure_msg / ensure_el)
     if (max_iter + 2 > h->cap_remaining) {
         dev_free(h->d_remaining);
         if (h->h_remaining) (void)hipHostFree(h->h_remaining);
@@ -1035,6 +1220,50 @@ int ensure_workspace(scaldpc_bp *h, int T, int G, bool want_post, int max_iter)
         h->cap_remaining = max_iter + 2;
     }
     return 0;
+}
+
+// message array of the tile path, G tiles
+int ensure_msg(scaldpc_bp *h, int G)
+{
+    if (G > h->cap_group) {
+        dev_free(h->d_msg); dev_free(h->d_scratch);
+        h->cap_group = 0;
+        SC_TRY(dev_alloc(&h->d_msg, (size_t)G * h->E * TW));
+        if (h->need_scratch) SC_TRY(dev_alloc(&h->d_scratch, (size_t)G * h->E * TW));
+        h->cap_group = G;
+    }
+    return 0;
+}
+
+// message + prefix arrays of the row-parallel path, nb codewords
+int ensure_el(scaldpc_bp *h, int nb)
+{
+    const size_t need = (size_t)nb * h->E;
+    if (need > h->cap_el || !h->d_emsg) {
+        dev_free(h->d_emsg);
+        h->cap_el = 0;
+        SC_TRY(dev_alloc(&h->d_emsg, need));
+        h->cap_el = need;
+    }
+    return 0;
+}
+
+// How many codewords the row-parallel kernels take (0 = none: use 64-codeword tiles).
+// Their cost grows with the codeword count (12 us per iteration for one codeword, +3.7 us per
+// further one with min-sum, 16 / +6.5 us with the tanh rule, HQC-128 bench graph), a tile's
+// does not (40 / 43 us): the default limit is where the two meet
+// (profiles/microbench/small_batch_latency.py).  SCALDPC_PATH=edge lifts the limit to a whole
+// tile, SCALDPC_PATH=stream disables the path (tests pin either).
+int el_limit(const scaldpc_bp *h, int method)
+{
+    if (h->el_waves == 0) return 0;  // empty graph, or a row / column wider than a wave
+    int lim = method == SCALDPC_BP_MIN_SUM ? 6 : 4;
+    if (const char *e = getenv("SCALDPC_EL_MAX")) lim = atoi(e);
+    if (const char *f = getenv("SCALDPC_PATH")) {
+        if (!strcmp(f, "stream")) lim = 0;
+        if (!strcmp(f, "edge")) lim = TW;
+    }
+    return std::max(0, std::min(lim, TW));
 }
 
 #define LAUNCH_CHECK() SC_HIP(hipGetLastError())
@@ -1091,6 +1320,36 @@ int launch_var(scaldpc_bp *h, int G, float *post_g, u64 *hard_g, const u64 *done
     return 0;
 }
 
+int launch_el_check(scaldpc_bp *h, int method, float alpha, int nb, const u64 *synd_g, const u64 *done_g,
+                    int skip_done, hipStream_t s, bool first)
+{
+    dim3 grid((h->m + 3) / 4, nb);
+#define EL_LAUNCH(M, F)                                                                                             \
+    hipLaunchKernelGGL((k_el_check<M, F>), grid, dim3(256), 0, s, h->d_row_ptr, h->d_col_idx, h->d_prior, h->d_emsg,  \
+                       synd_g, done_g, skip_done, h->m, h->E, alpha)
+    if (method == SCALDPC_BP_MIN_SUM) {
+        if (first) EL_LAUNCH(SCALDPC_BP_MIN_SUM, true); else EL_LAUNCH(SCALDPC_BP_MIN_SUM, false);
+    } else {
+        EL_LAUNCH(SCALDPC_BP_PRODUCT_SUM, false);
+    }
+#undef EL_LAUNCH
+    LAUNCH_CHECK();
+    return 0;
+}
+
+int launch_el_var(scaldpc_bp *h, int nb, float *post_g, u64 *hard_g, const u64 *done_g, int skip_done, int write_out,
+                  hipStream_t s)
+{
+    // grid.x a multiple of 8: block x lands on the same XCD for every codeword row, so an XCD's L2
+    // keeps its share of the slot table
+    const unsigned gx = (unsigned)(((h->el_waves + 3) / 4 + 7) / 8 * 8);
+    hipLaunchKernelGGL(k_el_var, dim3(gx, nb), dim3(256), 0, s, (const int2 *)h->d_el_slots, (const int2 *)h->d_el_winfo,
+                       h->d_var_list, h->el_waves, h->d_prior, h->d_emsg, post_g, hard_g, done_g, skip_done, h->E,
+                       write_out);
+    LAUNCH_CHECK();
+    return 0;
+}
+
 float alpha_for(float alpha, int it)
 {
     // ms_scaling_factor == 0 -> 1 - 2^-iter
@@ -1107,8 +1366,9 @@ struct TileState {
 // All iterations of the tile group [g0, g0+g) of `st`.  With defer_after > 0 the group
 // stops at the first poll point from that iteration on at which at most half of its
 // codewords are still running, and reports *deferred = true: those go to the compact pass.
+// el > 0: the group is ONE tile holding `el` codewords, decoded by the row-parallel kernels.
 int iterate_group(scaldpc_bp *h, const TileState &st, int g0, int g, int max_iter, int method, float alpha, bool early,
-                  int defer_after, hipStream_t s, bool *deferred)
+                  int defer_after, hipStream_t s, bool *deferred, int el = 0, int real_codewords = 0)
 {
     const int poll_every = 4;
     const int skip = early ? 1 : 0;
@@ -1120,15 +1380,24 @@ int iterate_group(scaldpc_bp *h, const TileState &st, int g0, int g, int max_ite
     *deferred = false;
     const bool fused = fused_init(h, method);
     if (h->E && !fused) {
-        hipLaunchKernelGGL(k_init_msg, dim3((unsigned)((h->E + 3) / 4), g), dim3(256), 0, s, h->d_col_idx, h->d_prior,
-                           h->d_msg, h->E);
+        if (el)
+            hipLaunchKernelGGL(k_el_init, dim3((unsigned)((h->E + 255) / 256), el), dim3(256), 0, s, h->d_col_idx,
+                               h->d_prior, h->d_emsg, h->E);
+        else
+            hipLaunchKernelGGL(k_init_msg, dim3((unsigned)((h->E + 3) / 4), g), dim3(256), 0, s, h->d_col_idx,
+                               h->d_prior, h->d_msg, h->E);
         LAUNCH_CHECK();
     }
     if (early) SC_HIP(hipMemsetAsync(h->d_remaining, 0, sizeof(int) * ((size_t)max_iter + 2), s));
     for (int it = 1; it <= max_iter; it++) {
         const bool last = it == max_iter;
-        SC_TRY(launch_check(h, method, alpha_for(alpha, it), g, synd_g, done_g, skip, s, fused && it == 1));
-        SC_TRY(launch_var(h, g, post_g, hard_g, done_g, skip, (early || last) ? 1 : 0, s));
+        if (el) {
+            SC_TRY(launch_el_check(h, method, alpha_for(alpha, it), el, synd_g, done_g, skip, s, fused && it == 1));
+            SC_TRY(launch_el_var(h, el, post_g, hard_g, done_g, skip, (early || last) ? 1 : 0, s));
+        } else {
+            SC_TRY(launch_check(h, method, alpha_for(alpha, it), g, synd_g, done_g, skip, s, fused && it == 1));
+            SC_TRY(launch_var(h, g, post_g, hard_g, done_g, skip, (early || last) ? 1 : 0, s));
+        }
         if (early || last) {
             hipLaunchKernelGGL(k_parity<true>, dim3((h->m + 4 * ROWS_PER_WAVE - 1) / (4 * ROWS_PER_WAVE), g), dim3(256), 0, s, h->d_row_ptr, h->d_col_idx,
                                hard_g, h->m, h->n, const_cast<u64 *>(synd_g), unsat_g, (const u64 *)done_g);
@@ -1145,7 +1414,10 @@ int iterate_group(scaldpc_bp *h, const TileState &st, int g0, int g, int max_ite
             if (rem == 0) break;
             // from `defer_after` on, any poll point may hand the stragglers over, provided the
             // restart (it iterations redone) is cheap next to what is still ahead
-            if (defer_after > 0 && it >= defer_after && 2 * it < max_iter && 2 * rem <= g * TW) {
+            // ... and the stragglers really get cheaper: fewer tiles, or few enough for the
+            // row-parallel kernels
+            const bool shrinks = (rem + TW - 1) / TW < g || (!el && rem <= el_limit(h, method));
+            if (defer_after > 0 && it >= defer_after && 2 * it < max_iter && 2 * rem <= real_codewords && shrinks) {
                 *deferred = true;
                 break;
             }
@@ -1166,14 +1438,15 @@ int run_core(scaldpc_bp *h, int batch, int T, int G, int max_iter, int method, f
                        h->d_iters);
     LAUNCH_CHECK();
     SC_HIP(hipMemsetAsync(h->d_hard, 0, sizeof(u64) * (size_t)T * h->n, s));
-    h->last_group = std::min(G, T);
+    h->last_group = 0;
     h->stat_deferred = 0;
+    h->stat_el = 0;
 
     // small graph: the LDS-resident single-launch decoder, plane I/O (Monte-Carlo entry points)
     {
         const size_t small_lds = (size_t)2 * h->E * sizeof(float) + (size_t)2 * h->n + h->m + 64;
         const char *force = getenv("SCALDPC_PATH");
-        if (small_lds <= 60 * 1024 && h->E > 0 && !(force && !strcmp(force, "stream"))) {
+        if (small_lds <= 60 * 1024 && h->E > 0 && !(force && (!strcmp(force, "stream") || !strcmp(force, "edge")))) {
 #define SMALL_PLANES(M)                                                                                              \
     hipLaunchKernelGGL((k_bp_small<M, true>), dim3(batch), dim3(256), small_lds, s, h->d_row_ptr, h->d_col_idx,         \
                        h->d_col_ptr, h->d_csc_edge, h->d_prior, h->m, h->n, (int)h->E, (const void *)h->d_synd,         \
@@ -1189,8 +1462,17 @@ int run_core(scaldpc_bp *h, int batch, int T, int G, int max_iter, int method, f
         }
     }
 
+    const int lim = el_limit(h, method);
+    const int el = (T == 1 && batch <= lim) ? batch : 0;  // a handful of codewords: row-parallel kernels
+    if (el)
+        SC_TRY(ensure_el(h, el));
+    else
+        SC_TRY(ensure_msg(h, std::min(G, T)));
+    h->last_group = el ? 0 : std::min(G, T);
+    h->stat_el = el;
+
     int defer_after = 0;
-    if (early) {
+    if (early && !el) {
         defer_after = 4;  // measured on the config-5 sweep: 4-5 best (177k trials/s), 8: 156k, 12: 136k
         if (const char *e = getenv("SCALDPC_COMPACT_AFTER")) defer_after = atoi(e);
         if (max_iter <= 2 * defer_after) defer_after = 0;  // nothing to gain
@@ -1202,7 +1484,8 @@ int run_core(scaldpc_bp *h, int batch, int T, int G, int max_iter, int method, f
     for (int g0 = 0; g0 < T; g0 += G) {
         const int g = std::min(G, T - g0);
         bool d = false;
-        SC_TRY(iterate_group(h, st, g0, g, max_iter, method, alpha, early, defer_after, s, &d));
+        const int real = std::min(batch - g0 * TW, g * TW);
+        SC_TRY(iterate_group(h, st, g0, g, max_iter, method, alpha, early, defer_after, s, &d, el, real));
         if (d) {
             any = true;
             for (int t = g0; t < g0 + g; t++) deferred_tile[t] = 1;
@@ -1257,9 +1540,15 @@ int run_core(scaldpc_bp *h, int batch, int T, int G, int max_iter, int method, f
     const TileState st2{h->d_synd2, h->d_hard2, h->d_done2, h->d_conv2, h->d_unsat2, h->d_iters2,
                         want_post ? h->d_post2 : nullptr};
     const int G2 = std::min(G, T2);
+    const int el2 = (T2 == 1 && batch2 <= lim) ? batch2 : 0;
+    if (el2)
+        SC_TRY(ensure_el(h, el2));
+    else
+        SC_TRY(ensure_msg(h, G2));
+    h->stat_el = el2;
     for (int g0 = 0; g0 < T2; g0 += G2) {
         bool d = false;
-        SC_TRY(iterate_group(h, st2, g0, std::min(G2, T2 - g0), max_iter, method, alpha, early, 0, s, &d));
+        SC_TRY(iterate_group(h, st2, g0, std::min(G2, T2 - g0), max_iter, method, alpha, early, 0, s, &d, el2, batch2));
     }
     hipLaunchKernelGGL(k_scatter_planes, dim3((h->n + 63) / 64, T), dim3(256), 0, s, h->d_hard, h->n, h->d_slot_of,
                        h->d_hard2);
@@ -1318,15 +1607,6 @@ int scaldpc_bp_create(int32_t m, int32_t n, int64_t nnz, const int32_t *row_ptr,
             cdeg[col_idx[e]]++;
         }
     }
-    // CSC permutation: edges grouped by column, ascending row (row-major scan keeps rows ascending)
-    std::vector<int> col_ptr(n + 1, 0), csc_edge((size_t)nnz), fill(n, 0);
-    for (int j = 0; j < n; j++) col_ptr[j + 1] = col_ptr[j] + cdeg[j];
-    for (int r = 0; r < m; r++)
-        for (int e = row_ptr[r]; e < row_ptr[r + 1]; e++) {
-            int j = col_idx[e];
-            csc_edge[(size_t)col_ptr[j] + fill[j]++] = e;
-        }
-
     scaldpc_bp *h = new (std::nothrow) scaldpc_bp();
     if (!h) return fail(SCALDPC_ENOMEM, "out of host memory");
     h->m = m;
@@ -1352,39 +1632,101 @@ int scaldpc_bp_create(int32_t m, int32_t n, int64_t nnz, const int32_t *row_ptr,
         h->identity_from = ident ? n - m : -1;
     }
 
-    int rc = 0;
-    auto up = [&](int **d, const int *src, size_t cnt) -> int {
-        SC_TRY(dev_alloc(d, cnt));
-        if (cnt) SC_HIP(hipMemcpy(*d, src, cnt * sizeof(int), hipMemcpyHostToDevice));
-        return 0;
+    // Every device-side graph array is a view into ONE allocation filled by ONE copy: the
+    // attack loop builds a new decoder per decode (hqc.py:694), so construction is on its
+    // critical path (a dozen hipMalloc + synchronous hipMemcpy pairs cost more than the decode).
+    const bool el = nnz > 0 && h->max_row_deg <= 64 && h->max_col_deg <= 64;
+    int el_waves = 0;
+    if (el) {  // row-parallel path: whole columns, in degree order, packed into waves of 64 lane slots
+        int used = 0;
+        for (size_t i = 0; i < hv.list.size(); i++) {
+            const int need = std::max(cdeg[hv.list[i]], 1);
+            if (used + need > 64) used = 0;
+            if (used == 0) el_waves++;
+            used += need;
+        }
+    }
+    std::vector<int> host;
+    auto reserve = [&](size_t cnt) {  // 256-byte aligned sections
+        const size_t off = host.size();
+        host.resize(off + (cnt + 63) / 64 * 64, 0);
+        return off;
     };
-    if (!rc) rc = up(&h->d_row_ptr, row_ptr, (size_t)m + 1);
-    if (!rc) rc = up(&h->d_col_idx, col_idx, (size_t)nnz);
-    if (!rc) rc = up(&h->d_col_ptr, col_ptr.data(), (size_t)n + 1);
-    if (!rc) rc = up(&h->d_csc_edge, csc_edge.data(), (size_t)nnz);
-    if (!rc) rc = up(&h->d_var_list, hv.list.data(), hv.list.size());
+    const size_t o_row_ptr = reserve((size_t)m + 1), o_col_idx = reserve((size_t)nnz), o_col_ptr = reserve((size_t)n + 1);
+    const size_t o_csc_edge = reserve((size_t)nnz), o_var_list = reserve(hv.list.size());
+    const size_t o_var_meta = reserve(4 * hv.list.size() + 4), o_csc_list = reserve((size_t)nnz + 1);
+    const size_t o_row_list = reserve(hr.list.size());
+    const size_t o_el_slots = reserve((size_t)el_waves * 128), o_el_winfo = reserve((size_t)el_waves * 2);
+    const size_t o_prior = reserve((size_t)n);
+    std::copy(row_ptr, row_ptr + m + 1, host.begin() + o_row_ptr);
+    std::copy(col_idx, col_idx + nnz, host.begin() + o_col_idx);
+    // CSC permutation: edges grouped by column, ascending row (row-major scan keeps rows ascending)
+    int *col_ptr = host.data() + o_col_ptr, *csc_edge = host.data() + o_csc_edge;
     {
-        std::vector<int> meta(4 * hv.list.size() + 4, 0), relaid((size_t)nnz + 1, 0);
+        std::vector<int> fill(n, 0);
+        for (int j = 0; j < n; j++) col_ptr[j + 1] = col_ptr[j] + cdeg[j];
+        for (int r = 0; r < m; r++)
+            for (int e = row_ptr[r]; e < row_ptr[r + 1]; e++) {
+                const int j = col_idx[e];
+                csc_edge[(size_t)col_ptr[j] + fill[j]++] = e;
+            }
+    }
+    std::copy(hv.list.begin(), hv.list.end(), host.begin() + o_var_list);
+    std::copy(hr.list.begin(), hr.list.end(), host.begin() + o_row_list);
+    {  // k_var: one packed descriptor per column and the edge lists in launch order
+        int *meta = host.data() + o_var_meta, *relaid = host.data() + o_csc_list;
         int pos = 0;
         for (size_t i = 0; i < hv.list.size(); i++) {
-            const int v = hv.list[i], d = col_ptr[v + 1] - col_ptr[v];
+            const int v = hv.list[i], d = cdeg[v];
             meta[4 * i + 0] = v;
             meta[4 * i + 1] = pos;
             meta[4 * i + 2] = d;
             for (int k = 0; k < d; k++) relaid[pos + k] = csc_edge[(size_t)col_ptr[v] + k];
             pos += d;
         }
-        if (!rc) rc = up(&h->d_var_meta, meta.data(), meta.size());
-        if (!rc) rc = up(&h->d_csc_list, relaid.data(), relaid.size());
     }
-    if (!rc) rc = up(&h->d_row_list, hr.list.data(), hr.list.size());
-    if (!rc) rc = dev_alloc(&h->d_prior, (size_t)n);
-    if (!rc && hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking) != hipSuccess)
-        rc = fail(SCALDPC_EHIP, "hipStreamCreate failed");
+    if (el) {
+        int *slots = host.data() + o_el_slots, *winfo = host.data() + o_el_winfo;
+        for (size_t i = 0; i < (size_t)el_waves * 64; i++) slots[2 * i] = -1;  // empty slot: no edge, not valid
+        int w = -1, used = 64;
+        for (size_t i = 0; i < hv.list.size(); i++) {
+            const int v = hv.list[i], d = cdeg[v], need = std::max(d, 1);
+            if (used + need > 64) {
+                w++;
+                used = 0;
+                winfo[2 * w + 0] = 0;
+                winfo[2 * w + 1] = (int)i;
+            }
+            winfo[2 * w] = std::max(winfo[2 * w], d);
+            for (int k = 0; k < need; k++) {
+                int *sl = slots + 2 * ((size_t)w * 64 + used + k);
+                sl[0] = d ? csc_edge[(size_t)col_ptr[v] + k] : -1;
+                sl[1] = used | (k << 6) | (d << 13) | (1 << 20);
+            }
+            used += need;
+        }
+        h->el_waves = el_waves;
+    }
+
+    int rc = dev_alloc(&h->d_graph, host.size());
+    if (!rc && hipMemcpy(h->d_graph, host.data(), host.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess)
+        rc = fail(SCALDPC_EHIP, "graph upload failed");
+    if (!rc) rc = stream_acquire(&h->own_stream, &h->device);
     if (rc) {
         scaldpc_bp_destroy(h);
         return rc;
     }
+    h->d_row_ptr = h->d_graph + o_row_ptr;
+    h->d_col_idx = h->d_graph + o_col_idx;
+    h->d_col_ptr = h->d_graph + o_col_ptr;
+    h->d_csc_edge = h->d_graph + o_csc_edge;
+    h->d_var_list = h->d_graph + o_var_list;
+    h->d_var_meta = h->d_graph + o_var_meta;
+    h->d_csc_list = h->d_graph + o_csc_list;
+    h->d_row_list = h->d_graph + o_row_list;
+    h->d_el_slots = h->d_graph + o_el_slots;
+    h->d_el_winfo = h->d_graph + o_el_winfo;
+    h->d_prior = (float *)(h->d_graph + o_prior);
     *out = h;
     return 0;
 }
@@ -1413,6 +1755,14 @@ int scaldpc_bp_last_compacted(scaldpc_bp *h, int64_t *count)
     if (!h || !count) return fail(SCALDPC_EINVAL, "NULL argument");
     std::lock_guard<std::mutex> lk(h->mu);
     *count = h->stat_deferred;
+    return 0;
+}
+
+int scaldpc_bp_last_row_parallel(scaldpc_bp *h, int64_t *count)
+{
+    if (!h || !count) return fail(SCALDPC_EINVAL, "NULL argument");
+    std::lock_guard<std::mutex> lk(h->mu);
+    *count = h->stat_el;
     return 0;
 }
 
@@ -1451,11 +1801,11 @@ int scaldpc_bp_decode_batch(scaldpc_bp *h, const uint8_t *in, int32_t input_kind
 
     // Small graph: the LDS-resident single-launch decoder (k_bp_small).
     const size_t small_lds = (size_t)2 * h->E * sizeof(float) + (size_t)2 * h->n + h->m + 64;
-    const char *force = getenv("SCALDPC_PATH");  // "stream" / "lds" pin a path (tests)
+    const char *force = getenv("SCALDPC_PATH");  // "stream" / "edge" / "lds" pin a path (tests)
     const bool small_fits = small_lds <= 60 * 1024 && h->E > 0;
     if (force && !strcmp(force, "lds") && !small_fits)
         return fail(SCALDPC_EINVAL, "SCALDPC_PATH=lds but the graph needs %zu B of LDS", small_lds);
-    if (small_fits && !(force && !strcmp(force, "stream"))) {
+    if (small_fits && !(force && (!strcmp(force, "stream") || !strcmp(force, "edge")))) {
         const uint8_t *din = in;
         uint8_t *dbits = out_bits, *dconv = out_conv;
         float *dllr = out_llr;
@@ -1763,9 +2113,7 @@ int scaldpc_bp_time_kernels(scaldpc_bp *h, int32_t iters, int32_t method, float 
 void scaldpc_bp_destroy(scaldpc_bp *h)
 {
     if (!h) return;
-    dev_free(h->d_row_ptr); dev_free(h->d_col_idx); dev_free(h->d_col_ptr); dev_free(h->d_csc_edge);
-    dev_free(h->d_var_list); dev_free(h->d_row_list); dev_free(h->d_prior);
-    dev_free(h->d_var_meta); dev_free(h->d_csc_list);
+    dev_free(h->d_graph);  // graph arrays and d_prior are views into it
     dev_free(h->d_msg); dev_free(h->d_scratch); dev_free(h->d_post);
     dev_free(h->d_synd); dev_free(h->d_recv); dev_free(h->d_hard); dev_free(h->d_done);
     dev_free(h->d_conv); dev_free(h->d_unsat); dev_free(h->d_iters); dev_free(h->d_remaining);
@@ -1773,9 +2121,10 @@ void scaldpc_bp_destroy(scaldpc_bp *h)
     dev_free(h->d_out_iters);
     dev_free(h->d_synd2); dev_free(h->d_hard2); dev_free(h->d_done2); dev_free(h->d_conv2); dev_free(h->d_unsat2);
     dev_free(h->d_iters2); dev_free(h->d_ids); dev_free(h->d_slot_of); dev_free(h->d_post2);
+    dev_free(h->d_emsg);
     dev_free(h->d_thr); dev_free(h->d_mc); dev_free(h->d_diff); dev_free(h->d_ylist); dev_free(h->d_succ);
     if (h->h_remaining) (void)hipHostFree(h->h_remaining);
-    if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
+    if (h->own_stream) stream_release(h->own_stream, h->device);
     delete h;
 }
 

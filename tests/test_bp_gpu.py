@@ -13,15 +13,17 @@ pytestmark = pytest.mark.gpu
 bp = importlib.import_module("sca-ldpc_amd.bp")
 
 
-@pytest.fixture(autouse=True, params=["auto", "stream"])
+@pytest.fixture(autouse=True, params=["auto", "stream", "edge"])
 def decode_path(request, monkeypatch):
-    """Every test runs twice: with the library's own choice (small graphs -> the LDS-resident
-    single-launch decoder, large ones -> the streaming kernels) and with the streaming kernels
-    forced, so both implementations face the same oracle."""
-    if request.param == "stream":
-        monkeypatch.setenv("SCALDPC_PATH", "stream")
-    else:
+    """Every test runs three times: with the library's own choice (small graphs -> the
+    LDS-resident single-launch decoder, a handful of codewords -> the row-parallel kernels,
+    otherwise 64-codeword tiles), with the tile kernels forced ("stream"), and with the
+    row-parallel kernels taking everything up to 64 codewords ("edge"; larger batches and
+    rows wider than 64 fall back to tiles), so all implementations face the same oracle."""
+    if request.param == "auto":
         monkeypatch.delenv("SCALDPC_PATH", raising=False)
+    else:
+        monkeypatch.setenv("SCALDPC_PATH", request.param)
     return request.param
 
 
@@ -268,6 +270,63 @@ def test_lds_path_is_taken_and_agrees_with_streaming(monkeypatch):
     dec = bp.bp_decoder(big, error_rate=0.01, max_iter=3)
     with pytest.raises(ValueError, match="LDS"):
         dec.decode_batch(np.zeros((1, big.m), dtype=np.uint8))
+
+
+@pytest.mark.parametrize("method", ["min_sum", "product_sum"])
+def test_row_parallel_path_is_taken_and_agrees_with_tiles(oracle, method, monkeypatch):
+    """A handful of codewords on a graph too large for LDS (the attack loop's single decode(),
+    hqc.py:708) go through the row-parallel kernels (wave = row, lane = edge): same bits,
+    posteriors, iteration counts and flags as the 64-codeword-tile kernels -- exactly --
+    for both input kinds, with and without early exit; ragged row degrees; +-inf priors."""
+    H, Hin, probs, msg, y = hqc_instance(2003, 11, 900, 9, 0.04, 64, seed=33)
+    probs = probs.copy()
+    probs[-7:] = 0.0  # certainty-1.0 checks
+    synd = H.syndrome(np.concatenate([y, np.zeros((64, 900), np.uint8)], axis=1))
+    for nb in (1, 3, 16, 17, 64):
+        for x in (synd[:nb], msg[:nb]):
+            for early in (True, False):
+                out = {}
+                for path in ("edge", "stream"):
+                    monkeypatch.setenv("SCALDPC_PATH", path)
+                    dec = bp.bp_decoder(H, max_iter=30, bp_method=method, channel_probs=probs)
+                    out[path] = dec.decode_batch(x, early_exit=early, want_llr=True)
+                    assert dec.last_row_parallel() == (nb if path == "edge" else 0)
+                    dec.close()
+                for k in ("bits", "llr", "iters", "converged"):
+                    assert np.array_equal(out["edge"][k], out["stream"][k]), (nb, early, k)
+    ref = oracle.bp_decode_batch(H, probs, msg[:64], 1, 30, ORACLE_METHOD[method], dtype="f32", threads=8,
+                                 early_exit=False)
+    compare(out["edge"], ref, method)  # nb = 64, received words, fixed iterations
+    # the library's own choice: a handful of codewords per call
+    monkeypatch.delenv("SCALDPC_PATH", raising=False)
+    dec = bp.bp_decoder(H, max_iter=30, bp_method=method, channel_probs=probs)
+    a = dec.decode_batch(msg[:4], early_exit=True, want_llr=True)
+    assert dec.last_row_parallel() == 4
+    dec.decode_batch(msg[:17], early_exit=True)
+    assert dec.last_row_parallel() == 0
+    one = dec.decode(msg[0])
+    assert dec.last_row_parallel() == 1 and np.array_equal(one, a["bits"][0])
+    dec.close()
+
+
+def test_compact_pass_hands_few_stragglers_to_row_parallel_kernels(oracle, monkeypatch):
+    """Early-exit call whose stragglers are few: the compact second pass decodes them with the
+    row-parallel kernels; results equal the pass-disabled run and the oracle."""
+    H, Hin, probs, msg, y = hqc_instance(997, 9, 450, 6, 0.03, 256, seed=21)
+    monkeypatch.setenv("SCALDPC_PATH", "edge")  # limit 64: whatever the straggler count, one tile of them qualifies
+    dec = bp.bp_decoder(H, max_iter=60, bp_method="product_sum", channel_probs=probs)
+    a = dec.decode_batch(msg, early_exit=True, want_llr=True)
+    nc, nr = dec.last_compacted(), dec.last_row_parallel()
+    assert nc > 0 and nr == (nc if nc <= 64 else 0), (nc, nr)
+    assert nc <= 64, "instance no longer exercises the hand-over; pick another seed"
+    monkeypatch.setenv("SCALDPC_COMPACT_AFTER", "0")
+    b = dec.decode_batch(msg, early_exit=True, want_llr=True)
+    assert dec.last_compacted() == 0 and dec.last_row_parallel() == 0
+    dec.close()
+    for k in ("bits", "llr", "iters", "converged"):
+        assert np.array_equal(a[k], b[k]), k
+    ref = oracle.bp_decode_batch(H, probs, msg, 1, 60, ORACLE_METHOD["product_sum"], dtype="f32", threads=8)
+    compare(a, ref, "product_sum")
 
 
 def test_device_io_equals_host_io():
