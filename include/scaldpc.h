@@ -78,6 +78,12 @@ const char *scaldpc_last_error(void);
 int scaldpc_version(void);
 int scaldpc_device_count(int *count);
 int scaldpc_set_device(int device);
+/* Device and pinned-host blocks (up to 64 MiB each, 512 MiB in total) released by destroyed
+ * handles are parked for the next handle instead of going through hipFree: the reference builds
+ * a new decoder per decode (simulate/hqc.py:694), and allocation would otherwise cost several
+ * times the decode.  scaldpc_trim() returns the parked blocks to the driver;
+ * SCALDPC_NO_CACHE=1 in the environment disables parking. */
+int scaldpc_trim(void);
 
 /* ------------------------------------------------------------------ binary BP */
 typedef struct scaldpc_bp scaldpc_bp;

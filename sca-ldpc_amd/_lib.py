@@ -41,6 +41,8 @@ def _declare(lib):
     lib.scaldpc_version.restype = C.c_int
     lib.scaldpc_device_count.argtypes = [p(C.c_int)]
     lib.scaldpc_set_device.argtypes = [C.c_int]
+    lib.scaldpc_trim.argtypes = []
+    lib.scaldpc_trim.restype = C.c_int
     lib.scaldpc_bp_create.argtypes = [C.c_int32, C.c_int32, C.c_int64, vp, vp, p(vp)]
     lib.scaldpc_bp_set_channel_probs.argtypes = [vp, vp]
     lib.scaldpc_bp_decode_batch.argtypes = [
@@ -113,6 +115,11 @@ def check(rc):
     if rc == ENOMEM:
         raise MemoryError(msg)
     raise ScaldpcError(f"[{rc}] {msg}")
+
+
+def trim():
+    """Return the device / pinned blocks parked by destroyed decoders to the driver."""
+    check(load().scaldpc_trim())
 
 
 def ptr(a):

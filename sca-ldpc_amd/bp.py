@@ -82,13 +82,14 @@ class BpDecoder:
         )
         self._h = h
         # priors, as the package resolves them: channel_probs wins over error_rate
-        cp = list(channel_probs) if channel_probs is not None else [None]
-        if len(cp) and cp[0] is not None:
-            if len(cp) != self.n:
+        # (no list() round trip: a 20 000-entry ndarray per decoder is the attack loop's normal case)
+        have_cp = channel_probs is not None and len(channel_probs) > 0 and channel_probs[0] is not None
+        if have_cp:
+            if len(channel_probs) != self.n:
                 raise ValueError(
                     f"The length of the channel probability vector must be eqaul to the block length n={self.n}."
                 )
-            probs = np.asarray(cp, dtype=np.float64)
+            probs = np.asarray(channel_probs, dtype=np.float64)
         elif error_rate is not None:
             probs = np.full(self.n, float(error_rate), dtype=np.float64)
         else:

@@ -36,6 +36,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
+#include <unordered_map>
 #include <vector>
 
 typedef unsigned long long u64;
@@ -56,7 +57,136 @@ int fail(int code, const char *fmt, ...)
     last_error() = buf;
     return code;
 }
+
+// ---- block cache behind dev_alloc / dev_free (see scaldpc_common.h) ----------------------
+namespace {
+struct Block {
+    size_t bytes;
+    int device;  // -1: pinned host memory
+};
+struct BlockCache {
+    std::mutex mu;
+    std::unordered_map<void *, Block> live;       // every block handed out and still owned by a handle
+    std::vector<std::pair<void *, Block>> idle;   // released, ready for reuse
+    size_t idle_bytes = 0;
+};
+BlockCache &block_cache()
+{
+    static BlockCache *c = new BlockCache();  // never destroyed: the HIP runtime may be gone at exit
+    return *c;
+}
+constexpr size_t CACHE_BLOCK_MAX = (size_t)64 << 20, CACHE_TOTAL_MAX = (size_t)512 << 20;
+thread_local bool tl_bypass = false;  // set while serving a handle that may still have asynchronous work in flight
+bool cache_enabled()
+{
+    static const bool on = getenv("SCALDPC_NO_CACHE") == nullptr;
+    return on && !tl_bypass;
+}
+void raw_free(void *p, const Block &b)
+{
+    if (b.device < 0)
+        (void)hipHostFree(p);
+    else
+        (void)hipFree(p);
+}
+}  // namespace
+
+// SCALDPC_POISON=1 (tests): every block handed out is filled with 0xFF first, so that code
+// relying on fresh or recycled memory being zero shows up as a wrong result
+int poison(void *p, size_t bytes, bool pinned_host)
+{
+    static const bool on = getenv("SCALDPC_POISON") != nullptr;
+    if (!on) return 0;
+    if (pinned_host) {
+        memset(p, 0xFF, bytes);
+    } else {
+        SC_HIP(hipMemset(p, 0xFF, bytes));
+        SC_HIP(hipDeviceSynchronize());
+    }
+    return 0;
+}
+
+CacheBypass::CacheBypass(bool on) : prev(tl_bypass) { tl_bypass = prev || on; }
+CacheBypass::~CacheBypass() { tl_bypass = prev; }
+
+int cached_alloc(void **p, size_t bytes, bool pinned_host)
+{
+    *p = nullptr;
+    bytes = (bytes + 255) / 256 * 256;
+    int dev = -1;
+    if (!pinned_host) SC_HIP(hipGetDevice(&dev));
+    BlockCache &bc = block_cache();
+    if (cache_enabled() && bytes <= CACHE_BLOCK_MAX) {
+        std::lock_guard<std::mutex> lk(bc.mu);
+        size_t best = bc.idle.size();
+        for (size_t i = 0; i < bc.idle.size(); i++) {  // smallest block that fits without wasting more than half
+            const Block &b = bc.idle[i].second;
+            if (b.device == dev && b.bytes >= bytes && b.bytes <= 2 * bytes + 4096 &&
+                (best == bc.idle.size() || b.bytes < bc.idle[best].second.bytes))
+                best = i;
+        }
+        if (best != bc.idle.size()) {
+            *p = bc.idle[best].first;
+            bc.live.emplace(*p, bc.idle[best].second);
+            const size_t got = bc.idle[best].second.bytes;
+            bc.idle_bytes -= got;
+            bc.idle.erase(bc.idle.begin() + best);
+            return poison(*p, got, pinned_host);
+        }
+    }
+    hipError_t e = pinned_host ? hipHostMalloc(p, bytes, hipHostMallocDefault) : hipMalloc(p, bytes);
+    if (e == hipErrorOutOfMemory) {  // give the parked blocks back and try once more
+        (void)hipGetLastError();
+        scaldpc_trim();
+        e = pinned_host ? hipHostMalloc(p, bytes, hipHostMallocDefault) : hipMalloc(p, bytes);
+    }
+    if (e != hipSuccess) {
+        *p = nullptr;
+        return fail(e == hipErrorOutOfMemory ? SCALDPC_ENOMEM : SCALDPC_EHIP, "allocation of %zu bytes failed: %s", bytes,
+                    hipGetErrorString(e));
+    }
+    {
+        std::lock_guard<std::mutex> lk(bc.mu);
+        bc.live.emplace(*p, Block{bytes, dev});
+    }
+    return poison(*p, bytes, pinned_host);
+}
+
+void cached_free(void *p)
+{
+    if (!p) return;
+    BlockCache &bc = block_cache();
+    Block b{0, 0};
+    {
+        std::lock_guard<std::mutex> lk(bc.mu);
+        auto it = bc.live.find(p);
+        if (it == bc.live.end()) return;  // not ours (cannot happen through dev_free)
+        b = it->second;
+        bc.live.erase(it);
+        if (cache_enabled() && b.bytes <= CACHE_BLOCK_MAX && bc.idle_bytes + b.bytes <= CACHE_TOTAL_MAX) {
+            bc.idle.emplace_back(p, b);
+            bc.idle_bytes += b.bytes;
+            return;
+        }
+    }
+    raw_free(p, b);
+}
+
 }  // namespace scaldpc
+
+extern "C" int scaldpc_trim(void)
+{
+    using namespace scaldpc;
+    BlockCache &bc = block_cache();
+    std::vector<std::pair<void *, Block>> drop;
+    {
+        std::lock_guard<std::mutex> lk(bc.mu);
+        drop.swap(bc.idle);
+        bc.idle_bytes = 0;
+    }
+    for (auto &d : drop) raw_free(d.first, d.second);
+    return 0;
+}
 
 using namespace scaldpc;
 
@@ -1095,6 +1225,10 @@ struct scaldpc_bp {
     int identity_from = -1;  // n - m if the last m columns of H are I_m (H = [Hin | I]), else -1
     hipStream_t own_stream = nullptr;
     int device = 0;  // the device the handle (and its stream) was created on
+    // Set by the first SCALDPC_F_ASYNC call and never cleared: work may be in flight when a later call
+    // (or destroy) releases a buffer, so this handle's blocks go back through hipFree (which
+    // waits for the device) instead of being parked for immediate reuse.
+    bool async_used = false;
     int last_group = 0;  // tiles of the last decoded group (for scaldpc_bp_time_kernels)
     std::mutex mu;
 };
@@ -1141,29 +1275,38 @@ void stream_release(hipStream_t s, int dev)
 // bucket b holds nodes with bounds[b-1] < deg <= bounds[b]; beyond the last bound -> generic (maxd 0)
 void build_buckets(const std::vector<int> &deg, const int *bounds, int nb, bool keep_isolated, HostBuckets &out)
 {
-    std::vector<std::vector<int>> tmp(nb + 1);
-    for (int i = 0; i < (int)deg.size(); i++) {
-        // an isolated check has nothing to send; an isolated VARIABLE still owes its
-        // posterior (= prior) and hard decision, so it stays in the smallest bucket
-        if (deg[i] == 0 && !keep_isolated) continue;
-        int b = 0;
-        while (b < nb && deg[i] > bounds[b]) b++;
-        tmp[b].push_back(i);
-    }
+    // Stable counting sort by degree (ascending node id inside a degree): bucket lists are
+    // degree ranges of it, so neighbouring waves of a launch run the same exact-degree code
+    // path.  (Decoder construction is on the attack loop's critical path: no per-bucket
+    // vectors, no comparison sort.)
+    const int n = (int)deg.size();
+    int maxdeg = 0;
+    for (int d : deg) maxdeg = std::max(maxdeg, d);
+    std::vector<int> start(maxdeg + 2, 0);
+    for (int d : deg) start[d + 1]++;
+    for (int d = 0; d <= maxdeg; d++) start[d + 1] += start[d];
+    std::vector<int> order(n), cursor(start.begin(), start.end() - 1);
+    for (int i = 0; i < n; i++) order[cursor[deg[i]]++] = i;
     out.list.clear();
+    out.list.reserve(n);
+    out.has_generic = false;
     Buckets &bk = out.bk;
     memset(&bk, 0, sizeof bk);
-    for (int b = 0; b <= nb; b++) {
-        if (tmp[b].empty()) continue;
-        const int i = bk.nb++;
-        bk.maxd[i] = b < nb ? bounds[b] : 0;
-        if (b == nb) out.has_generic = true;
-        // neighbouring waves of a launch should run the same exact-degree code path
-        std::stable_sort(tmp[b].begin(), tmp[b].end(), [&](int x, int y) { return deg[x] < deg[y]; });
-        bk.off[i] = (int)out.list.size();
-        bk.cnt[i] = (int)tmp[b].size();
-        bk.blk[i + 1] = bk.blk[i] + (bk.cnt[i] + 3) / 4;
-        out.list.insert(out.list.end(), tmp[b].begin(), tmp[b].end());
+    int lo = keep_isolated ? 0 : 1;  // smallest degree of the bucket being formed
+    for (int b = 0; b <= nb && lo <= maxdeg; b++) {
+        const int hi = b < nb ? std::min(bounds[b], maxdeg) : maxdeg;  // beyond the last bound: any-degree fallback
+        if (hi < lo) continue;
+        const int first = start[lo], last = start[hi + 1];
+        if (last > first) {
+            const int i = bk.nb++;
+            bk.maxd[i] = b < nb ? bounds[b] : 0;
+            if (b == nb) out.has_generic = true;
+            bk.off[i] = (int)out.list.size();
+            bk.cnt[i] = last - first;
+            bk.blk[i + 1] = bk.blk[i] + (bk.cnt[i] + 3) / 4;
+            out.list.insert(out.list.end(), order.begin() + first, order.begin() + last);
+        }
+        lo = hi + 1;
     }
 }
 
@@ -1212,11 +1355,11 @@ int ensure_workspace(scaldpc_bp *h, int T, int G, bool want_post, int max_iter)
     (void)G;  // the message arrays are allocated by the path that uses them (ensure_msg / ensure_el)
     if (max_iter + 2 > h->cap_remaining) {
         dev_free(h->d_remaining);
-        if (h->h_remaining) (void)hipHostFree(h->h_remaining);
+        cached_free(h->h_remaining);
         h->h_remaining = nullptr;
         h->cap_remaining = 0;
         SC_TRY(dev_alloc(&h->d_remaining, (size_t)max_iter + 2));
-        SC_HIP(hipHostMalloc((void **)&h->h_remaining, sizeof(int) * ((size_t)max_iter + 2), hipHostMallocDefault));
+        SC_TRY(cached_alloc((void **)&h->h_remaining, sizeof(int) * ((size_t)max_iter + 2), true));
         h->cap_remaining = max_iter + 2;
     }
     return 0;
@@ -1569,6 +1712,23 @@ int run_core(scaldpc_bp *h, int batch, int T, int G, int max_iter, int method, f
 // ===========================================================================
 // C ABI
 // ===========================================================================
+#include <chrono>
+#define TMARK(name)                                                                                   \
+    do {                                                                                              \
+        static const bool on__ = getenv("SCALDPC_TIMING") != nullptr;                                 \
+        if (on__) {                                                                                   \
+            auto now__ = std::chrono::steady_clock::now();                                            \
+            fprintf(stderr, "[create] %-10s %8.1f us\n", name,                                        \
+                    std::chrono::duration<double, std::micro>(now__ - tmark_last()).count());         \
+            tmark_last() = now__;                                                                     \
+        }                                                                                             \
+    } while (0)
+static std::chrono::steady_clock::time_point &tmark_last()
+{
+    static thread_local std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
+    return t;
+}
+
 extern "C" {
 
 const char *scaldpc_last_error(void) { return last_error().c_str(); }
@@ -1596,6 +1756,7 @@ int scaldpc_bp_create(int32_t m, int32_t n, int64_t nnz, const int32_t *row_ptr,
         return fail(SCALDPC_EINVAL, "bad graph arguments (m=%d n=%d nnz=%lld)", m, n, (long long)nnz);
     if (nnz > 0x7fffffffLL) return fail(SCALDPC_EINVAL, "nnz too large");
     if (row_ptr[0] != 0 || row_ptr[m] != nnz) return fail(SCALDPC_EINVAL, "row_ptr does not span [0, nnz]");
+    TMARK("start");
     std::vector<int> rdeg(m), cdeg(n, 0);
     for (int r = 0; r < m; r++) {
         if (row_ptr[r + 1] < row_ptr[r]) return fail(SCALDPC_EINVAL, "row_ptr not monotone at row %d", r);
@@ -1615,11 +1776,13 @@ int scaldpc_bp_create(int32_t m, int32_t n, int64_t nnz, const int32_t *row_ptr,
     h->max_row_deg = m ? *std::max_element(rdeg.begin(), rdeg.end()) : 0;
     h->max_col_deg = *std::max_element(cdeg.begin(), cdeg.end());
 
+    TMARK("validate");
     static const int vb[] = {1, 2, 4, 8, 16, 32, 64};
     static const int rb[] = {2, 4, 8, 16, 32, 64};
     HostBuckets hv, hr;
     build_buckets(cdeg, vb, 7, true, hv);
     build_buckets(rdeg, rb, 6, false, hr);
+    TMARK("buckets");
     h->var_bk = hv.bk;
     h->row_bk = hr.bk;
     h->need_scratch = hv.has_generic || hr.has_generic;
@@ -1646,10 +1809,18 @@ int scaldpc_bp_create(int32_t m, int32_t n, int64_t nnz, const int32_t *row_ptr,
             used += need;
         }
     }
-    std::vector<int> host;
+    // host staging buffer, reused by the thread's later constructions (fresh pages for a
+    // 5 MB vector cost more page-fault time than everything else here)
+    struct Staging {
+        int *p = nullptr;
+        size_t cap = 0;
+        ~Staging() { free(p); }
+    };
+    static thread_local Staging stage;
+    size_t total = 0;
     auto reserve = [&](size_t cnt) {  // 256-byte aligned sections
-        const size_t off = host.size();
-        host.resize(off + (cnt + 63) / 64 * 64, 0);
+        const size_t off = total;
+        total += (cnt + 63) / 64 * 64;
         return off;
     };
     const size_t o_row_ptr = reserve((size_t)m + 1), o_col_idx = reserve((size_t)nnz), o_col_ptr = reserve((size_t)n + 1);
@@ -1658,60 +1829,89 @@ int scaldpc_bp_create(int32_t m, int32_t n, int64_t nnz, const int32_t *row_ptr,
     const size_t o_row_list = reserve(hr.list.size());
     const size_t o_el_slots = reserve((size_t)el_waves * 128), o_el_winfo = reserve((size_t)el_waves * 2);
     const size_t o_prior = reserve((size_t)n);
-    std::copy(row_ptr, row_ptr + m + 1, host.begin() + o_row_ptr);
-    std::copy(col_idx, col_idx + nnz, host.begin() + o_col_idx);
-    // CSC permutation: edges grouped by column, ascending row (row-major scan keeps rows ascending)
-    int *col_ptr = host.data() + o_col_ptr, *csc_edge = host.data() + o_csc_edge;
-    {
-        std::vector<int> fill(n, 0);
-        for (int j = 0; j < n; j++) col_ptr[j + 1] = col_ptr[j] + cdeg[j];
-        for (int r = 0; r < m; r++)
-            for (int e = row_ptr[r]; e < row_ptr[r + 1]; e++) {
-                const int j = col_idx[e];
-                csc_edge[(size_t)col_ptr[j] + fill[j]++] = e;
-            }
+    if (total > stage.cap) {
+        free(stage.p);
+        stage.cap = 0;
+        stage.p = (int *)malloc(total * sizeof(int));
+        if (!stage.p) {
+            delete h;
+            return fail(SCALDPC_ENOMEM, "out of host memory");
+        }
+        stage.cap = total;
     }
-    std::copy(hv.list.begin(), hv.list.end(), host.begin() + o_var_list);
-    std::copy(hr.list.begin(), hr.list.end(), host.begin() + o_row_list);
+    int *const host = stage.p;  // not cleared: every word a kernel reads is written below
+    TMARK("reserve");
+    std::copy(row_ptr, row_ptr + m + 1, host + o_row_ptr);
+    std::copy(col_idx, col_idx + nnz, host + o_col_idx);
+    // CSC permutation: edges grouped by column, ascending row (row-major scan keeps rows ascending)
+    int *col_ptr = host + o_col_ptr, *csc_edge = host + o_csc_edge;
+    {
+        col_ptr[0] = 0;
+        for (int j = 0; j < n; j++) col_ptr[j + 1] = col_ptr[j] + cdeg[j];
+        std::vector<int> cursor(col_ptr, col_ptr + n);
+        for (int e = 0; e < (int)nnz; e++) csc_edge[cursor[col_idx[e]]++] = e;
+    }
+    TMARK("csc");
+    std::copy(hv.list.begin(), hv.list.end(), host + o_var_list);
+    std::copy(hr.list.begin(), hr.list.end(), host + o_row_list);
     {  // k_var: one packed descriptor per column and the edge lists in launch order
-        int *meta = host.data() + o_var_meta, *relaid = host.data() + o_csc_list;
+        int *meta = host + o_var_meta, *relaid = host + o_csc_list;
         int pos = 0;
         for (size_t i = 0; i < hv.list.size(); i++) {
             const int v = hv.list[i], d = cdeg[v];
             meta[4 * i + 0] = v;
             meta[4 * i + 1] = pos;
             meta[4 * i + 2] = d;
+            meta[4 * i + 3] = 0;
             for (int k = 0; k < d; k++) relaid[pos + k] = csc_edge[(size_t)col_ptr[v] + k];
             pos += d;
         }
     }
+    TMARK("meta");
     if (el) {
-        int *slots = host.data() + o_el_slots, *winfo = host.data() + o_el_winfo;
-        for (size_t i = 0; i < (size_t)el_waves * 64; i++) slots[2 * i] = -1;  // empty slot: no edge, not valid
+        int *slots = host + o_el_slots, *winfo = host + o_el_winfo;
         int w = -1, used = 64;
+        auto pad_wave = [&]() {  // empty slots: no edge, not valid
+            if (w >= 0)
+                for (; used < 64; used++) {
+                    slots[2 * ((size_t)w * 64 + used)] = -1;
+                    slots[2 * ((size_t)w * 64 + used) + 1] = 0;
+                }
+        };
         for (size_t i = 0; i < hv.list.size(); i++) {
             const int v = hv.list[i], d = cdeg[v], need = std::max(d, 1);
             if (used + need > 64) {
+                pad_wave();
                 w++;
                 used = 0;
                 winfo[2 * w + 0] = 0;
                 winfo[2 * w + 1] = (int)i;
             }
             winfo[2 * w] = std::max(winfo[2 * w], d);
+            const int *ce = csc_edge + col_ptr[v];
+            int *sl = slots + 2 * ((size_t)w * 64 + used);
+            const int tag = used | (d << 13) | (1 << 20);
             for (int k = 0; k < need; k++) {
-                int *sl = slots + 2 * ((size_t)w * 64 + used + k);
-                sl[0] = d ? csc_edge[(size_t)col_ptr[v] + k] : -1;
-                sl[1] = used | (k << 6) | (d << 13) | (1 << 20);
+                sl[2 * k] = d ? ce[k] : -1;
+                sl[2 * k + 1] = tag | (k << 6);
             }
             used += need;
         }
+        pad_wave();
         h->el_waves = el_waves;
     }
-
-    int rc = dev_alloc(&h->d_graph, host.size());
-    if (!rc && hipMemcpy(h->d_graph, host.data(), host.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess)
+    TMARK("slots");
+    int rc = dev_alloc(&h->d_graph, total);
+    if (!rc && hipMemcpy(h->d_graph, host, total * sizeof(int), hipMemcpyHostToDevice) != hipSuccess)
         rc = fail(SCALDPC_EHIP, "graph upload failed");
+    if (stage.cap > ((size_t)64 << 20)) {  // do not sit on more than 256 MB
+        free(stage.p);
+        stage.p = nullptr;
+        stage.cap = 0;
+    }
+    TMARK("upload");
     if (!rc) rc = stream_acquire(&h->own_stream, &h->device);
+    TMARK("stream");
     if (rc) {
         scaldpc_bp_destroy(h);
         return rc;
@@ -1793,6 +1993,8 @@ int scaldpc_bp_decode_batch(scaldpc_bp *h, const uint8_t *in, int32_t input_kind
     if ((flags & SCALDPC_F_ASYNC) && (!dev_io || early))
         return fail(SCALDPC_EINVAL, "SCALDPC_F_ASYNC needs DEVICE_IO and no EARLY_EXIT (early exit polls the device)");
     hipStream_t s = stream ? (hipStream_t)stream : h->own_stream;
+    if (flags & SCALDPC_F_ASYNC) h->async_used = true;
+    CacheBypass guard(h->async_used);
 
     const int T = (batch + TW - 1) / TW;
     if (T > 65535) return fail(SCALDPC_EINVAL, "batch %d too large for one call (max %d)", batch, 65535 * TW);
@@ -1992,6 +2194,7 @@ int scaldpc_mc_fer_run(scaldpc_bp *h, int64_t first_trial, int32_t batch, uint64
 {
     SC_TRY(mc_common_args(h, batch, method, alpha, out_success));
     std::lock_guard<std::mutex> lk(h->mu);
+    CacheBypass guard(h->async_used);
     if (!h->have_prior) return fail(SCALDPC_EINVAL, "channel probabilities not set");
     if (max_iter <= 0) max_iter = h->n;
     const bool dev_io = flags & SCALDPC_F_DEVICE_IO, early = flags & SCALDPC_F_EARLY_EXIT;
@@ -2028,6 +2231,7 @@ int scaldpc_mc_hqc_run(scaldpc_bp *h, int32_t omega, double eps, int64_t first_t
 {
     SC_TRY(mc_common_args(h, batch, method, alpha, out_success));
     std::lock_guard<std::mutex> lk(h->mu);
+    CacheBypass guard(h->async_used);
     if (!h->have_prior) return fail(SCALDPC_EINVAL, "channel probabilities not set");
     if (h->identity_from < 0) return fail(SCALDPC_EINVAL, "parity-check matrix is not of the form [Hin | I] (hqc.py:680)");
     const int N = h->identity_from;
@@ -2123,7 +2327,8 @@ void scaldpc_bp_destroy(scaldpc_bp *h)
     dev_free(h->d_iters2); dev_free(h->d_ids); dev_free(h->d_slot_of); dev_free(h->d_post2);
     dev_free(h->d_emsg);
     dev_free(h->d_thr); dev_free(h->d_mc); dev_free(h->d_diff); dev_free(h->d_ylist); dev_free(h->d_succ);
-    if (h->h_remaining) (void)hipHostFree(h->h_remaining);
+    CacheBypass guard(h->async_used);
+    cached_free(h->h_remaining);
     if (h->own_stream) stream_release(h->own_stream, h->device);
     delete h;
 }

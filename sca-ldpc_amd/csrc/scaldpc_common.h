@@ -28,19 +28,34 @@ int fail(int code, const char *fmt, ...);
         if (rc__) return rc__;  \
     } while (0)
 
+// Device / pinned-host memory through a small per-process cache of released blocks
+// (scaldpc_bp.hip): the reference builds a NEW decoder for every decode (hqc.py:694), and a
+// handle's ~20 hipMalloc / hipFree pairs (hipFree synchronises the device) cost several times
+// the decode itself.  Blocks up to 64 MiB are parked on release (at most 512 MiB in total,
+// scaldpc_trim() returns them to the driver, SCALDPC_NO_CACHE=1 disables the cache); larger
+// ones go straight to hipMalloc / hipFree.  Memory comes back uninitialised either way.
+int cached_alloc(void **p, size_t bytes, bool pinned_host);
+void cached_free(void *p);
+// While alive on a thread, released blocks go to hipFree / hipHostFree (which wait for the
+// device) instead of the cache: used when a handle may have asynchronous work in flight.
+struct CacheBypass {
+    explicit CacheBypass(bool on);
+    ~CacheBypass();
+    bool prev;
+};
+
 template <typename T>
 inline int dev_alloc(T **p, size_t count)
 {
     *p = nullptr;
     if (count == 0) count = 1;
-    SC_HIP(hipMalloc((void **)p, count * sizeof(T)));
-    return 0;
+    return cached_alloc((void **)p, count * sizeof(T), false);
 }
 
 template <typename T>
 inline void dev_free(T *&p)
 {
-    if (p) (void)hipFree(p);
+    if (p) cached_free((void *)p);
     p = nullptr;
 }
 

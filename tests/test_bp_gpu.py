@@ -329,6 +329,31 @@ def test_compact_pass_hands_few_stragglers_to_row_parallel_kernels(oracle, monke
     compare(a, ref, "product_sum")
 
 
+def test_decoder_per_decode_pattern_and_block_cache(oracle, monkeypatch, decode_path):
+    """The attack loop builds a NEW decoder for every decode (hqc.py:694) on a graph that grows
+    by a few rows each time: destroyed decoders park their device blocks for the next one.
+    Results must not depend on what the recycled memory held (compare with the cache
+    disabled... in a fresh library state that is the first iteration), trim() must be harmless."""
+    if decode_path != "auto":
+        pytest.skip("path-independent")
+    lib = importlib.import_module("sca-ldpc_amd._lib")
+    outs = []
+    for rep, R in enumerate((700, 700, 720, 650, 700)):
+        H, Hin, probs, msg, y = hqc_instance(1499, 9, R, 7, 0.03, 3, seed=5)  # same seed: nested row sets differ only by R
+        dec = bp.bp_decoder(H, max_iter=40, bp_method="product_sum", channel_probs=probs)
+        got = dec.decode_batch(msg, early_exit=True, want_llr=True)
+        single = dec.decode(msg[0])
+        assert np.array_equal(single, got["bits"][0])
+        dec.close()
+        ref = oracle.bp_decode_batch(H, probs, msg, 1, 40, ORACLE_METHOD["product_sum"], dtype="f32", threads=4)
+        compare(got, ref, "product_sum")
+        outs.append((R, got))
+        if rep == 2:
+            lib.trim()
+    for k in ("bits", "llr", "iters", "converged"):
+        assert np.array_equal(outs[0][1][k], outs[1][1][k]) and np.array_equal(outs[0][1][k], outs[4][1][k]), k
+
+
 def test_device_io_equals_host_io():
     """SCALDPC_F_DEVICE_IO (what bench.py uses: torch tensors' data_ptr(), nothing crosses
     PCIe) must give the same outputs as the host-buffer path, on the caller's stream."""
