@@ -122,11 +122,17 @@ int scaldpc_bp_set_tile_group(scaldpc_bp *h, int32_t tiles);
  * (stragglers of mostly-converged tile groups; results are identical either way;
  * environment SCALDPC_COMPACT_AFTER=0 disables the pass, =k moves the decision point). */
 int scaldpc_bp_last_compacted(scaldpc_bp *h, int64_t *count);
-/* Number of codewords the last call decoded with the row-parallel kernels (wave = one row of
- * one codeword, lane = edge; taken for calls -- or compact passes -- of at most 6 (min-sum) / 4
- * (tanh rule) codewords on graphs too large for LDS: the single decode() of hqc.py:708).  Results are identical to
- * the 64-codeword-tile kernels; SCALDPC_PATH=stream disables, =edge extends to 64. */
-int scaldpc_bp_last_row_parallel(scaldpc_bp *h, int64_t *count);
+/* Path statistics of the last call, out[4]:
+ *   out[0] = scaldpc_bp_last_compacted
+ *   out[1] = codewords decoded with the row-parallel kernels (wave = one row of one codeword,
+ *            lane = edge; taken for calls -- or compact passes -- of at most 6 (min-sum) / 4
+ *            (tanh rule) codewords on graphs too large for LDS: the single decode() of
+ *            hqc.py:708).  Results are identical to the 64-codeword-tile kernels;
+ *            SCALDPC_PATH=stream disables the path, =edge extends it to 64 codewords
+ *   out[2] = deepest compaction level reached (0 = none; stragglers of a compact pass are
+ *            compacted again, up to 3 levels)
+ *   out[3] = reserved (0) */
+int scaldpc_bp_last_stats(scaldpc_bp *h, int64_t *out);
 void scaldpc_bp_destroy(scaldpc_bp *h);
 
 /* ------------------------------------------- Monte-Carlo helpers on the device (K6) */

@@ -52,8 +52,8 @@ def _declare(lib):
     lib.scaldpc_bp_set_tile_group.argtypes = [vp, C.c_int32]
     lib.scaldpc_bp_last_compacted.argtypes = [vp, p(C.c_int64)]
     lib.scaldpc_bp_last_compacted.restype = C.c_int
-    lib.scaldpc_bp_last_row_parallel.argtypes = [vp, p(C.c_int64)]
-    lib.scaldpc_bp_last_row_parallel.restype = C.c_int
+    lib.scaldpc_bp_last_stats.argtypes = [vp, p(C.c_int64)]
+    lib.scaldpc_bp_last_stats.restype = C.c_int
     lib.scaldpc_bp_destroy.argtypes = [vp]
     lib.scaldpc_bp_destroy.restype = None
     lib.scaldpc_mc_fer_run.argtypes = [

@@ -241,11 +241,15 @@ class BpDecoder:
         _lib.check(self._lib.scaldpc_bp_last_compacted(self._h, C.byref(c)))
         return int(c.value)
 
+    def last_stats(self):
+        """Path statistics of the last call: codewords handed to the compact pass, codewords decoded
+        with the row-parallel (lane = edge) kernels, deepest compaction level reached."""
+        out = (C.c_int64 * 4)()
+        _lib.check(self._lib.scaldpc_bp_last_stats(self._h, out))
+        return {"compacted": int(out[0]), "row_parallel": int(out[1]), "levels": int(out[2])}
+
     def last_row_parallel(self):
-        """Codewords the last call decoded with the row-parallel (lane = edge) kernels."""
-        c = C.c_int64()
-        _lib.check(self._lib.scaldpc_bp_last_row_parallel(self._h, C.byref(c)))
-        return int(c.value)
+        return self.last_stats()["row_parallel"]
 
     def set_tile_group(self, tiles):
         _lib.check(self._lib.scaldpc_bp_set_tile_group(self._h, int(tiles)))

@@ -1209,11 +1209,17 @@ struct scaldpc_bp {
     size_t cap_mc = 0, cap_ylist = 0, cap_succ = 0, cap_diff = 0;
     bool thr_valid = false;
     // compact second pass over stragglers (early-exit runs)
-    int cap_tiles2 = 0;
-    u64 *d_synd2 = nullptr, *d_hard2 = nullptr, *d_done2 = nullptr, *d_conv2 = nullptr, *d_unsat2 = nullptr;
-    int *d_iters2 = nullptr, *d_ids = nullptr, *d_slot_of = nullptr;
-    float *d_post2 = nullptr;
-    size_t cap_post2 = 0, cap_slot_of = 0;
+    // (level k re-decodes the stragglers of level k-1 in dense tiles of their own; level 0 = the call's arrays)
+    struct Level {
+        int cap_tiles = 0;
+        u64 *synd = nullptr, *hard = nullptr, *done = nullptr, *conv = nullptr, *unsat = nullptr;
+        int *iters = nullptr, *ids = nullptr, *slot_of = nullptr;
+        float *post = nullptr;
+        size_t cap_post = 0, cap_slot_of = 0;
+    };
+    static constexpr int MAX_LEVELS = 3;
+    Level lv[MAX_LEVELS + 1];  // [0] unused
+    long stat_levels = 0;      // deepest compact level the last call reached
     long stat_deferred = 0;  // codewords re-decoded by the compact pass in the last call
     // row-parallel path (a handful of codewords): per-codeword message / prefix arrays [codeword][edge]
     float *d_emsg = nullptr;
@@ -1569,10 +1575,106 @@ int iterate_group(scaldpc_bp *h, const TileState &st, int g0, int g, int max_ite
     return 0;
 }
 
+// One compaction level: the `batch` codewords of `st` (T tiles), all iterations of one
+// cache-resident tile group after the other.  In early-exit runs the stragglers of
+// mostly-converged groups are gathered into dense tiles of their own and re-decoded from their
+// inputs one level down (codewords are independent and BP is deterministic: identical
+// results), and that level may shed its own stragglers again -- on the config-5 sweep the
+// second level drops the codewords that needed 5-7 iterations and leaves the ~0.5 % that never
+// converge to run their 100 iterations in 3 tiles instead of 11.
+int decode_level(scaldpc_bp *h, int lvl, const TileState &st, int batch, int T, int G, int max_iter, int method,
+                 float alpha, bool early, bool want_post, hipStream_t s)
+{
+    const int lim = el_limit(h, method);
+    const int el = (T == 1 && batch <= lim) ? batch : 0;  // a handful of codewords: row-parallel kernels
+    const int Gl = std::min(G, T);
+    if (el)
+        SC_TRY(ensure_el(h, el));
+    else
+        SC_TRY(ensure_msg(h, Gl));
+    if (lvl == 0) h->last_group = el ? 0 : Gl;
+    if (el) h->stat_el = el;
+    h->stat_levels = lvl;
+
+    int defer_after = 0;
+    if (early && !el && lvl < scaldpc_bp::MAX_LEVELS) {
+        defer_after = 4;  // measured on the config-5 sweep: 4-5 best (177k trials/s), 8: 156k, 12: 136k
+        if (const char *e = getenv("SCALDPC_COMPACT_AFTER")) defer_after = atoi(e);
+        if (max_iter <= 2 * defer_after) defer_after = 0;  // nothing to gain
+    }
+    std::vector<char> deferred_tile(T, 0);
+    bool any = false;
+    for (int g0 = 0; g0 < T; g0 += Gl) {
+        const int g = std::min(Gl, T - g0);
+        const int real = std::min(batch - g0 * TW, g * TW);
+        bool d = false;
+        SC_TRY(iterate_group(h, st, g0, g, max_iter, method, alpha, early, defer_after, s, &d, el, real));
+        if (d) {
+            any = true;
+            for (int t = g0; t < g0 + g; t++) deferred_tile[t] = 1;
+        }
+    }
+    if (!any) return 0;
+
+    // ---- the stragglers, one level down --------------------------------------------------
+    std::vector<u64> done_h(T);
+    SC_HIP(hipMemcpyAsync(done_h.data(), st.done, sizeof(u64) * T, hipMemcpyDeviceToHost, s));
+    SC_HIP(hipStreamSynchronize(s));
+    std::vector<int> ids, slot_of((size_t)T * TW, -1);
+    for (int t = 0; t < T; t++) {
+        if (!deferred_tile[t]) continue;
+        for (int c = 0; c < TW; c++) {
+            const long b = (long)t * TW + c;
+            if (b < batch && !((done_h[t] >> c) & 1)) {
+                slot_of[b] = (int)ids.size();
+                ids.push_back((int)b);
+            }
+        }
+    }
+    const int batch2 = (int)ids.size();
+    if (batch2 == 0) return 0;
+    if (lvl == 0) h->stat_deferred = batch2;
+    const int T2 = (batch2 + TW - 1) / TW;
+    ids.resize((size_t)T2 * TW, -1);
+    scaldpc_bp::Level &L = h->lv[lvl + 1];
+    if (T2 > L.cap_tiles) {
+        dev_free(L.synd); dev_free(L.hard); dev_free(L.done); dev_free(L.conv); dev_free(L.unsat);
+        dev_free(L.iters); dev_free(L.ids);
+        L.cap_tiles = 0;
+        SC_TRY(dev_alloc(&L.synd, (size_t)T2 * h->m));
+        SC_TRY(dev_alloc(&L.hard, (size_t)T2 * h->n));
+        SC_TRY(dev_alloc(&L.done, (size_t)T2));
+        SC_TRY(dev_alloc(&L.conv, (size_t)T2));
+        SC_TRY(dev_alloc(&L.unsat, (size_t)T2));
+        SC_TRY(dev_alloc(&L.iters, (size_t)T2 * TW));
+        SC_TRY(dev_alloc(&L.ids, (size_t)T2 * TW));
+        L.cap_tiles = T2;
+    }
+    SC_TRY(grow(&L.slot_of, &L.cap_slot_of, (size_t)T * TW));
+    if (want_post) SC_TRY(grow(&L.post, &L.cap_post, (size_t)T2 * h->n * TW));
+    SC_HIP(hipMemcpyAsync(L.ids, ids.data(), sizeof(int) * ids.size(), hipMemcpyHostToDevice, s));
+    SC_HIP(hipMemcpyAsync(L.slot_of, slot_of.data(), sizeof(int) * slot_of.size(), hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(k_gather_planes, dim3((h->m + 63) / 64, T2), dim3(256), 0, s, st.synd, h->m, L.ids, L.synd);
+    LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_init_state, dim3(T2), dim3(64), 0, s, batch2, max_iter, L.done, L.conv, L.unsat, L.iters);
+    LAUNCH_CHECK();
+    SC_HIP(hipMemsetAsync(L.hard, 0, sizeof(u64) * (size_t)T2 * h->n, s));
+    SC_HIP(hipStreamSynchronize(s));  // ids / slot_of are locals, and the level below reuses the stream
+    const TileState st2{L.synd, L.hard, L.done, L.conv, L.unsat, L.iters, want_post ? L.post : nullptr};
+    SC_TRY(decode_level(h, lvl + 1, st2, batch2, T2, G, max_iter, method, alpha, early, want_post, s));
+    hipLaunchKernelGGL(k_scatter_planes, dim3((h->n + 63) / 64, T), dim3(256), 0, s, st.hard, h->n, L.slot_of, L.hard);
+    LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_scatter_state, dim3(T), dim3(64), 0, s, st.iters, st.conv, L.slot_of, L.iters, L.conv);
+    LAUNCH_CHECK();
+    if (want_post) {
+        hipLaunchKernelGGL(k_scatter_post, dim3(h->n, T), dim3(64), 0, s, st.post, h->n, L.slot_of, L.post);
+        LAUNCH_CHECK();
+    }
+    return 0;
+}
+
 // The decode proper, on inputs already staged as planes (h->d_synd; h->d_recv when the
-// caller wants e XOR v): state reset, then all iterations of one cache-resident tile
-// group after the other; in early-exit runs, stragglers of mostly-converged groups are
-// re-decoded from their inputs in a compact second pass (identical results).
+// caller wants e XOR v): state reset, then decode_level.
 // Results stay on the device (h->d_hard / d_post / d_conv / d_iters).
 int run_core(scaldpc_bp *h, int batch, int T, int G, int max_iter, int method, float alpha, bool early,
              bool want_post, hipStream_t s)
@@ -1584,6 +1686,7 @@ int run_core(scaldpc_bp *h, int batch, int T, int G, int max_iter, int method, f
     h->last_group = 0;
     h->stat_deferred = 0;
     h->stat_el = 0;
+    h->stat_levels = 0;
 
     // small graph: the LDS-resident single-launch decoder, plane I/O (Monte-Carlo entry points)
     {
@@ -1604,107 +1707,9 @@ int run_core(scaldpc_bp *h, int batch, int T, int G, int max_iter, int method, f
             return 0;
         }
     }
-
-    const int lim = el_limit(h, method);
-    const int el = (T == 1 && batch <= lim) ? batch : 0;  // a handful of codewords: row-parallel kernels
-    if (el)
-        SC_TRY(ensure_el(h, el));
-    else
-        SC_TRY(ensure_msg(h, std::min(G, T)));
-    h->last_group = el ? 0 : std::min(G, T);
-    h->stat_el = el;
-
-    int defer_after = 0;
-    if (early && !el) {
-        defer_after = 4;  // measured on the config-5 sweep: 4-5 best (177k trials/s), 8: 156k, 12: 136k
-        if (const char *e = getenv("SCALDPC_COMPACT_AFTER")) defer_after = atoi(e);
-        if (max_iter <= 2 * defer_after) defer_after = 0;  // nothing to gain
-    }
     const TileState st{h->d_synd, h->d_hard, h->d_done, h->d_conv, h->d_unsat, h->d_iters,
                        want_post ? h->d_post : nullptr};
-    std::vector<char> deferred_tile(T, 0);
-    bool any = false;
-    for (int g0 = 0; g0 < T; g0 += G) {
-        const int g = std::min(G, T - g0);
-        bool d = false;
-        const int real = std::min(batch - g0 * TW, g * TW);
-        SC_TRY(iterate_group(h, st, g0, g, max_iter, method, alpha, early, defer_after, s, &d, el, real));
-        if (d) {
-            any = true;
-            for (int t = g0; t < g0 + g; t++) deferred_tile[t] = 1;
-        }
-    }
-    if (!any) return 0;
-
-    // ---- compact second pass ---------------------------------------------------------
-    std::vector<u64> done_h(T);
-    SC_HIP(hipMemcpyAsync(done_h.data(), h->d_done, sizeof(u64) * T, hipMemcpyDeviceToHost, s));
-    SC_HIP(hipStreamSynchronize(s));
-    std::vector<int> ids, slot_of((size_t)T * TW, -1);
-    for (int t = 0; t < T; t++) {
-        if (!deferred_tile[t]) continue;
-        for (int c = 0; c < TW; c++) {
-            const long b = (long)t * TW + c;
-            if (b < batch && !((done_h[t] >> c) & 1)) {
-                slot_of[b] = (int)ids.size();
-                ids.push_back((int)b);
-            }
-        }
-    }
-    const int batch2 = (int)ids.size();
-    if (batch2 == 0) return 0;
-    h->stat_deferred = batch2;
-    const int T2 = (batch2 + TW - 1) / TW;
-    ids.resize((size_t)T2 * TW, -1);
-    if (T2 > h->cap_tiles2) {
-        dev_free(h->d_synd2); dev_free(h->d_hard2); dev_free(h->d_done2); dev_free(h->d_conv2); dev_free(h->d_unsat2);
-        dev_free(h->d_iters2); dev_free(h->d_ids);
-        h->cap_tiles2 = 0;
-        SC_TRY(dev_alloc(&h->d_synd2, (size_t)T2 * h->m));
-        SC_TRY(dev_alloc(&h->d_hard2, (size_t)T2 * h->n));
-        SC_TRY(dev_alloc(&h->d_done2, (size_t)T2));
-        SC_TRY(dev_alloc(&h->d_conv2, (size_t)T2));
-        SC_TRY(dev_alloc(&h->d_unsat2, (size_t)T2));
-        SC_TRY(dev_alloc(&h->d_iters2, (size_t)T2 * TW));
-        SC_TRY(dev_alloc(&h->d_ids, (size_t)T2 * TW));
-        h->cap_tiles2 = T2;
-    }
-    SC_TRY(grow(&h->d_slot_of, &h->cap_slot_of, (size_t)T * TW));
-    if (want_post) SC_TRY(grow(&h->d_post2, &h->cap_post2, (size_t)T2 * h->n * TW));
-    SC_HIP(hipMemcpyAsync(h->d_ids, ids.data(), sizeof(int) * ids.size(), hipMemcpyHostToDevice, s));
-    SC_HIP(hipMemcpyAsync(h->d_slot_of, slot_of.data(), sizeof(int) * slot_of.size(), hipMemcpyHostToDevice, s));
-    hipLaunchKernelGGL(k_gather_planes, dim3((h->m + 63) / 64, T2), dim3(256), 0, s, h->d_synd, h->m, h->d_ids,
-                       h->d_synd2);
-    LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_init_state, dim3(T2), dim3(64), 0, s, batch2, max_iter, h->d_done2, h->d_conv2, h->d_unsat2,
-                       h->d_iters2);
-    LAUNCH_CHECK();
-    SC_HIP(hipMemsetAsync(h->d_hard2, 0, sizeof(u64) * (size_t)T2 * h->n, s));
-    const TileState st2{h->d_synd2, h->d_hard2, h->d_done2, h->d_conv2, h->d_unsat2, h->d_iters2,
-                        want_post ? h->d_post2 : nullptr};
-    const int G2 = std::min(G, T2);
-    const int el2 = (T2 == 1 && batch2 <= lim) ? batch2 : 0;
-    if (el2)
-        SC_TRY(ensure_el(h, el2));
-    else
-        SC_TRY(ensure_msg(h, G2));
-    h->stat_el = el2;
-    for (int g0 = 0; g0 < T2; g0 += G2) {
-        bool d = false;
-        SC_TRY(iterate_group(h, st2, g0, std::min(G2, T2 - g0), max_iter, method, alpha, early, 0, s, &d, el2, batch2));
-    }
-    hipLaunchKernelGGL(k_scatter_planes, dim3((h->n + 63) / 64, T), dim3(256), 0, s, h->d_hard, h->n, h->d_slot_of,
-                       h->d_hard2);
-    LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_scatter_state, dim3(T), dim3(64), 0, s, h->d_iters, h->d_conv, h->d_slot_of, h->d_iters2,
-                       h->d_conv2);
-    LAUNCH_CHECK();
-    if (want_post) {
-        hipLaunchKernelGGL(k_scatter_post, dim3(h->n, T), dim3(64), 0, s, h->d_post, h->n, h->d_slot_of, h->d_post2);
-        LAUNCH_CHECK();
-    }
-    SC_HIP(hipStreamSynchronize(s));  // ids / slot_of are locals
-    return 0;
+    return decode_level(h, 0, st, batch, T, G, max_iter, method, alpha, early, want_post, s);
 }
 
 }  // namespace
@@ -1958,11 +1963,14 @@ int scaldpc_bp_last_compacted(scaldpc_bp *h, int64_t *count)
     return 0;
 }
 
-int scaldpc_bp_last_row_parallel(scaldpc_bp *h, int64_t *count)
+int scaldpc_bp_last_stats(scaldpc_bp *h, int64_t *out)
 {
-    if (!h || !count) return fail(SCALDPC_EINVAL, "NULL argument");
+    if (!h || !out) return fail(SCALDPC_EINVAL, "NULL argument");
     std::lock_guard<std::mutex> lk(h->mu);
-    *count = h->stat_el;
+    out[0] = h->stat_deferred;
+    out[1] = h->stat_el;
+    out[2] = h->stat_levels;
+    out[3] = 0;
     return 0;
 }
 
@@ -2323,8 +2331,10 @@ void scaldpc_bp_destroy(scaldpc_bp *h)
     dev_free(h->d_conv); dev_free(h->d_unsat); dev_free(h->d_iters); dev_free(h->d_remaining);
     dev_free(h->d_in); dev_free(h->d_out_bits); dev_free(h->d_out_conv); dev_free(h->d_out_llr);
     dev_free(h->d_out_iters);
-    dev_free(h->d_synd2); dev_free(h->d_hard2); dev_free(h->d_done2); dev_free(h->d_conv2); dev_free(h->d_unsat2);
-    dev_free(h->d_iters2); dev_free(h->d_ids); dev_free(h->d_slot_of); dev_free(h->d_post2);
+    for (auto &L : h->lv) {
+        dev_free(L.synd); dev_free(L.hard); dev_free(L.done); dev_free(L.conv); dev_free(L.unsat);
+        dev_free(L.iters); dev_free(L.ids); dev_free(L.slot_of); dev_free(L.post);
+    }
     dev_free(h->d_emsg);
     dev_free(h->d_thr); dev_free(h->d_mc); dev_free(h->d_diff); dev_free(h->d_ylist); dev_free(h->d_succ);
     CacheBypass guard(h->async_used);

@@ -231,6 +231,7 @@ def test_straggler_compaction_is_invisible(oracle, method, monkeypatch, decode_p
     dec.set_tile_group(3)  # several groups, a ragged last one
     a = dec.decode_batch(msg, early_exit=True, want_llr=True)
     assert 0 < dec.last_compacted() < 350  # the pass actually ran, on a minority
+    assert dec.last_stats()["levels"] >= 1
     monkeypatch.setenv("SCALDPC_COMPACT_AFTER", "0")
     b = dec.decode_batch(msg, early_exit=True, want_llr=True)
     assert dec.last_compacted() == 0

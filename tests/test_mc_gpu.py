@@ -51,6 +51,30 @@ def test_hqc_run(oracle, eps):
     assert r["success"].mean() > 0.3
 
 
+def test_config5_sweep_sheds_stragglers_twice(monkeypatch):
+    """BASELINE config 5 (HQC-128 graph, eps = 0.05, tanh rule, early exit, max_iter 100): the
+    stragglers of the first pass (codewords needing 5+ iterations) are re-decoded in dense tiles,
+    and that pass sheds the few that never converge once more, so they run their 100 iterations in
+    a fraction of the tiles.  Success flags and iteration counts must equal the run with
+    compaction disabled."""
+    import json, os
+
+    rows = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "hqc_first_rows.json")))
+    H, Hin, _ = S.codes.hqc_bench_graph("hqc128", rows["N17669_W50_s0"])
+    N, omega = S.codes.HQC_PARAMS["hqc128"]
+    probs = np.concatenate([np.full(N, omega / N), np.full(H.m, 0.05)])
+    dec = bp.bp_decoder(H, max_iter=100, bp_method="product_sum", channel_probs=probs)
+    a = dec.mc_hqc_run(8192, omega=omega, eps=0.05, seed=7)
+    st = dec.last_stats()
+    assert st["compacted"] > 0 and st["levels"] >= 2, st
+    monkeypatch.setenv("SCALDPC_COMPACT_AFTER", "0")
+    b = dec.mc_hqc_run(8192, omega=omega, eps=0.05, seed=7)
+    assert dec.last_stats()["levels"] == 0
+    dec.close()
+    assert np.array_equal(a["success"], b["success"]) and np.array_equal(a["iters"], b["iters"])
+    assert (a["iters"] == 100).sum() > 0 and 0.7 < a["success"].mean() < 0.9
+
+
 def test_hqc_run_needs_identity_block():
     g = S.codes.rep_code_graph(9)
     dec = bp.bp_decoder(g, error_rate=0.1)
