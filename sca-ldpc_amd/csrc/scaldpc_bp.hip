@@ -277,16 +277,18 @@ __global__ __launch_bounds__(64) void k_unpack_state(const u64 *__restrict__ con
 // ---------------------------------------------------------------------------
 // parity of bit planes along the rows of H.
 //   CHECK = false: synd[t][r] = XOR_v bits[t][v]          (received-vector mode: s = H v)
-//   CHECK = true : unsat[t] |= synd[t][r] ^ XOR_v bits    (convergence test H e == s)
-// A wave takes ROWS_PER_WAVE consecutive rows of one tile, one row per step with its lanes
-// over the row's edges: the column indices of a row are one coalesced read, the 8-byte
+//   CHECK = true : unsat[t][w] = OR_r (synd[t][r] ^ XOR_v bits) over wave w's rows (convergence test H e == s)
+// A wave takes ROWS_PER_WAVE consecutive rows of one tile, all in flight at once, its lanes
+// over a row's edges: the column indices of a row are one coalesced read, the 8-byte
 // plane words are gathered from L2 (n x 8 B per tile: 173 KB at HQC-128), the row parity is
-// an XOR butterfly over the wave; mismatches are OR-ed in a register and cost one atomic per
-// wave at the end.  (The first version walked a row per THREAD: 51 dependent, uncoalesced
-// index reads each -- 27.7 us per launch in early-exit runs, a fifth of their GPU time.)
+// an XOR butterfly over the wave.  Every wave stores its OR of mismatches in its own slot
+// (k_finalize folds the slots): no atomics, so the launch can be as wide as the row count
+// allows.  (History: a row per THREAD -- 51 dependent, uncoalesced index reads -- 27.7 us per
+// launch on the bench graph; 16 rows per wave one after the other with one atomicOr per wave,
+// 19 us, latency-bound at one wave per SIMD; this form: see DESIGN.md.)
 // grid (ceil(m / (4*ROWS_PER_WAVE)), T), block 256.
 // ---------------------------------------------------------------------------
-constexpr int ROWS_PER_WAVE = 16;
+constexpr int ROWS_PER_WAVE = 4;
 
 template <bool CHECK>
 __global__ __launch_bounds__(256) void k_parity(const int *__restrict__ row_ptr, const int *__restrict__ col_idx,
@@ -296,27 +298,47 @@ __global__ __launch_bounds__(256) void k_parity(const int *__restrict__ row_ptr,
     const int lane = threadIdx.x & 63;
     const int t = blockIdx.y;
     if (CHECK && done[t] == ~0ull) return;  // whole tile frozen
-    const int r0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * ROWS_PER_WAVE;
+    const int wv = blockIdx.x * 4 + (threadIdx.x >> 6);  // wave index inside the tile
+    const int r0 = wv * ROWS_PER_WAVE;
     const u64 *bt = bits + (size_t)t * n;
     u64 bad = 0;
-    for (int r = r0; r < min(r0 + ROWS_PER_WAVE, m); r++) {
-        const int e0 = rfl(row_ptr[r]), e1 = rfl(row_ptr[r + 1]);
-        u64 a = 0;
-        for (int e = e0 + lane; e < e1; e += 64) a ^= bt[col_idx[e]];
+    // IL rows in flight: their index loads and plane gathers are independent, only the xor
+    // butterflies are not
+    constexpr int IL = 4;
+    const int rend = min(r0 + ROWS_PER_WAVE, m);
+    for (int rb = r0; rb < rend; rb += IL) {
+        u64 a[IL];
+        int ea[IL], eb[IL];
 #pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) a ^= __shfl_xor(a, off);
-        if (CHECK)
-            bad |= a ^ synd[(size_t)t * m + r];
-        else if (lane == 0)
-            synd[(size_t)t * m + r] = a;
+        for (int i = 0; i < IL; i++) {
+            const int r = min(rb + i, rend - 1);
+            ea[i] = rfl(row_ptr[r]) + lane;
+            eb[i] = rb + i < rend ? rfl(row_ptr[r + 1]) : 0;
+        }
+#pragma unroll
+        for (int i = 0; i < IL; i++) a[i] = ea[i] < eb[i] ? bt[col_idx[ea[i]]] : 0ull;  // first 64 edges of each row
+#pragma unroll
+        for (int i = 0; i < IL; i++)
+            for (int e = ea[i] + 64; e < eb[i]; e += 64) a[i] ^= bt[col_idx[e]];  // rows wider than a wave
+#pragma unroll
+        for (int i = 0; i < IL; i++) {
+            const int r = rb + i;
+            if (r >= rend) break;
+            u64 x = a[i];
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) x ^= __shfl_xor(x, off);
+            if (CHECK)
+                bad |= x ^ synd[(size_t)t * m + r];
+            else if (lane == 0)
+                synd[(size_t)t * m + r] = x;
+        }
     }
-    if (CHECK && lane == 0 && bad) atomicOr(unsat + t, bad);
+    if (CHECK && lane == 0) unsat[(size_t)t * (gridDim.x * 4) + wv] = bad;
 }
 
 // per-tile state reset.  grid T, block 64.
 __global__ __launch_bounds__(64) void k_init_state(int batch, int max_iter, u64 *__restrict__ done,
-                                                   u64 *__restrict__ conv, u64 *__restrict__ unsat,
-                                                   int *__restrict__ iters)
+                                                   u64 *__restrict__ conv, int *__restrict__ iters)
 {
     const int t = blockIdx.x, c = threadIdx.x;
     const long b = (long)t * TW + c;
@@ -325,7 +347,6 @@ __global__ __launch_bounds__(64) void k_init_state(int batch, int max_iter, u64 
     if (c == 0) {
         done[t] = pad;
         conv[t] = 0;
-        unsat[t] = 0;
     }
 }
 
@@ -334,26 +355,31 @@ __global__ __launch_bounds__(64) void k_init_state(int batch, int max_iter, u64 
 //           frozen: done bit set, iters = it, its outputs are no longer overwritten.
 //   latch = 0 (fixed iterations): only record whether the FINAL decision satisfies.
 // *remaining += number of codewords still running.
+// unsat: the `pw` per-wave words k_parity<true> just wrote for each tile (a tile it skipped
+// is all done: whatever its stale words say, nothing is latched).
 __global__ __launch_bounds__(64) void k_finalize(int it, int latch, u64 *__restrict__ done, u64 *__restrict__ conv,
-                                                 u64 *__restrict__ unsat, int *__restrict__ iters,
+                                                 const u64 *__restrict__ unsat, int pw, int *__restrict__ iters,
                                                  int *__restrict__ remaining)
 {
     const int t = blockIdx.x, c = threadIdx.x;
-    const u64 uw = unsat[t];
     const u64 dw = done[t];
+    u64 uw = 0;
+    if (dw != ~0ull) {
+        for (int i = c; i < pw; i += 64) uw |= unsat[(size_t)t * pw + i];
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) uw |= __shfl_xor(uw, off);
+    }
     const u64 newly = ~dw & ~uw;
     if (latch) {
         if ((newly >> c) & 1) iters[(long)t * TW + c] = it;
         if (c == 0) {
             done[t] = dw | newly;
             conv[t] |= newly;
-            unsat[t] = 0;
             const int rem = __popcll(~(dw | newly));
             if (rem) atomicAdd(remaining, rem);
         }
     } else if (c == 0) {
         conv[t] = newly;  // dw = padding here
-        unsat[t] = 0;
     }
 }
 
@@ -453,8 +479,11 @@ __device__ __forceinline__ float llr_from_compl(float U)  // 2 atanh(1 - U) = lo
 // U' = U + u (1 - U), one rounding (the oracle's method 3 uses fmaf in the same places)
 __device__ __forceinline__ float compl_step(float U, float u) { return fmaf(u, 1.0f - U, U); }
 
-template <int DEG>
-__device__ __forceinline__ void check_tanh_row(float *p, unsigned sbit)
+// FIRST: iteration 1 takes its inputs from the priors of the row's columns (cidx = the row's
+// slice of col_idx), so the message array needs no initialisation pass and is not read.
+template <int DEG, bool FIRST>
+__device__ __forceinline__ void check_tanh_row(float *p, unsigned sbit, const float *__restrict__ prior,
+                                               const int *__restrict__ cidx)
 {
     // EXACT degree: straight-line code, no per-edge branches (a predicated `k < deg` unroll
     // makes every edge its own basic block, and the compiler then waits for all memory
@@ -464,7 +493,7 @@ __device__ __forceinline__ void check_tanh_row(float *p, unsigned sbit)
     // the sign of exact zeros can differ from the `x < 0` convention), finally the output.
     float uu[DEG], pre[DEG];
 #pragma unroll
-    for (int k = 0; k < DEG; k++) uu[k] = p[(size_t)k * TW];
+    for (int k = 0; k < DEG; k++) uu[k] = FIRST ? prior[rfl(cidx[k])] : p[(size_t)k * TW];
     unsigned acc = sbit << 31;  // running XOR of sign bits, syndrome folded in
     float U = 0.0f;
 #pragma unroll
@@ -519,11 +548,12 @@ __device__ __forceinline__ void check_tanh_row_generic(float *p, float *sc, int 
 // CAP = largest degree compiled in (the register budget follows the widest instantiation,
 // so graphs with narrow rows get the high-occupancy build).
 // grid (bk.blk[nb], G), block 256 = 4 rows of one bucket.
-template <int CAP>
+template <int CAP, bool FIRST>
 __global__ __launch_bounds__(256) void k_check_tanh(Buckets bk, const int *__restrict__ list,
                                                     const int *__restrict__ row_ptr, float *msg, float *scratch,
                                                     const u64 *__restrict__ synd, const u64 *__restrict__ done,
-                                                    int skip_done, int m, long E)
+                                                    int skip_done, int m, long E, const int *__restrict__ col_idx,
+                                                    const float *__restrict__ prior)
 {
     const int lane = threadIdx.x & 63;
     const int tl = blockIdx.y;
@@ -539,9 +569,9 @@ __global__ __launch_bounds__(256) void k_check_tanh(Buckets bk, const int *__res
     float *p = msg + base;
     const unsigned sbit = (unsigned)(synd[(size_t)tl * m + r] >> lane) & 1u;
     // dispatch on the row's exact degree (wave-uniform); CAP bounds what is compiled in
-#define TR(D)                                                  \
-    case D:                                                    \
-        if constexpr (D <= CAP) check_tanh_row<D>(p, sbit);    \
+#define TR(D)                                                                              \
+    case D:                                                                                \
+        if constexpr (D <= CAP) check_tanh_row<D, FIRST>(p, sbit, prior, col_idx + e0);    \
         break;
 #define TR8(D) TR(D) TR(D + 1) TR(D + 2) TR(D + 3) TR(D + 4) TR(D + 5) TR(D + 6) TR(D + 7)
     if (bk.maxd[b] == 0) {
@@ -856,7 +886,7 @@ __device__ __forceinline__ float readlane_f(float v, int l)
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));
 }
 
-// tanh rule only (min-sum's first check pass reads the priors).  grid (ceil(E/256), nb).
+// unused by default (both rules' first check pass reads the priors); kept for rows the fused form does not cover.  grid (ceil(E/256), nb).
 __global__ __launch_bounds__(256) void k_el_init(const int *__restrict__ col_idx, const float *__restrict__ prior,
                                                  float *__restrict__ emsg, long E)
 {
@@ -864,7 +894,7 @@ __global__ __launch_bounds__(256) void k_el_init(const int *__restrict__ col_idx
     if (e < E) emsg[(size_t)blockIdx.y * E + e] = prior[col_idx[e]];
 }
 
-// METHOD as in the C ABI; FIRST: inputs are the priors (min-sum, iteration 1).
+// METHOD as in the C ABI; FIRST: inputs are the priors (iteration 1).
 // grid (ceil(m/4), nb), block 256 = 4 rows of codeword blockIdx.y.
 template <int METHOD, bool FIRST>
 __global__ __launch_bounds__(256) void k_el_check(const int *__restrict__ row_ptr, const int *__restrict__ col_idx,
@@ -1338,6 +1368,9 @@ int auto_group(const scaldpc_bp *h, int T)
     return std::max(1, std::min(g, T));
 }
 
+// waves per tile of a k_parity launch = words per tile of the unsat arrays
+int parity_waves(const scaldpc_bp *h) { return (h->m + 4 * ROWS_PER_WAVE - 1) / (4 * ROWS_PER_WAVE) * 4; }
+
 int ensure_workspace(scaldpc_bp *h, int T, int G, bool want_post, int max_iter)
 {
     if (T > h->cap_tiles) {
@@ -1350,7 +1383,7 @@ int ensure_workspace(scaldpc_bp *h, int T, int G, bool want_post, int max_iter)
         SC_TRY(dev_alloc(&h->d_hard, (size_t)T * h->n));
         SC_TRY(dev_alloc(&h->d_done, (size_t)T));
         SC_TRY(dev_alloc(&h->d_conv, (size_t)T));
-        SC_TRY(dev_alloc(&h->d_unsat, (size_t)T));
+        SC_TRY(dev_alloc(&h->d_unsat, (size_t)T * parity_waves(h)));
         SC_TRY(dev_alloc(&h->d_iters, (size_t)T * TW));
         h->cap_tiles = T;
     }
@@ -1417,8 +1450,12 @@ int el_limit(const scaldpc_bp *h, int method)
 
 #define LAUNCH_CHECK() SC_HIP(hipGetLastError())
 
-// min-sum needs no message initialisation pass: its first check update reads the priors
-bool fused_init(const scaldpc_bp *h, int method) { return method == SCALDPC_BP_MIN_SUM && h->E > 0; }
+// No message initialisation pass: the first check update reads the priors (v2c = prior of the
+// edge's column by definition).  The tanh rule's any-degree fallback (rows wider than 64) keeps it.
+bool fused_init(const scaldpc_bp *h, int method)
+{
+    return h->E > 0 && (method == SCALDPC_BP_MIN_SUM || h->max_row_deg <= ROW_CAP);
+}
 
 int launch_check(scaldpc_bp *h, int method, float alpha, int G, const u64 *synd_g, const u64 *done_g, int skip_done,
                  hipStream_t s, bool first = false)
@@ -1437,15 +1474,17 @@ int launch_check(scaldpc_bp *h, int method, float alpha, int G, const u64 *synd_
 #undef MS_LAUNCH
     } else {
         dim3 grid(h->row_bk.blk[h->row_bk.nb], G);
-        if (h->max_row_deg <= 16)
-            hipLaunchKernelGGL(k_check_tanh<16>, grid, dim3(256), 0, s, h->row_bk, h->d_row_list, h->d_row_ptr, h->d_msg,
-                               h->d_scratch, synd_g, done_g, skip_done, h->m, h->E);
-        else if (h->max_row_deg <= 32)
-            hipLaunchKernelGGL(k_check_tanh<32>, grid, dim3(256), 0, s, h->row_bk, h->d_row_list, h->d_row_ptr, h->d_msg,
-                               h->d_scratch, synd_g, done_g, skip_done, h->m, h->E);
-        else
-            hipLaunchKernelGGL(k_check_tanh<64>, grid, dim3(256), 0, s, h->row_bk, h->d_row_list, h->d_row_ptr, h->d_msg,
-                               h->d_scratch, synd_g, done_g, skip_done, h->m, h->E);
+#define TANH_LAUNCH(CAP, F)                                                                                         \
+    hipLaunchKernelGGL((k_check_tanh<CAP, F>), grid, dim3(256), 0, s, h->row_bk, h->d_row_list, h->d_row_ptr, h->d_msg, \
+                       h->d_scratch, synd_g, done_g, skip_done, h->m, h->E, h->d_col_idx, h->d_prior)
+        if (h->max_row_deg <= 16) {
+            if (first) TANH_LAUNCH(16, true); else TANH_LAUNCH(16, false);
+        } else if (h->max_row_deg <= 32) {
+            if (first) TANH_LAUNCH(32, true); else TANH_LAUNCH(32, false);
+        } else {
+            if (first) TANH_LAUNCH(64, true); else TANH_LAUNCH(64, false);
+        }
+#undef TANH_LAUNCH
     }
     LAUNCH_CHECK();
     return 0;
@@ -1479,7 +1518,7 @@ int launch_el_check(scaldpc_bp *h, int method, float alpha, int nb, const u64 *s
     if (method == SCALDPC_BP_MIN_SUM) {
         if (first) EL_LAUNCH(SCALDPC_BP_MIN_SUM, true); else EL_LAUNCH(SCALDPC_BP_MIN_SUM, false);
     } else {
-        EL_LAUNCH(SCALDPC_BP_PRODUCT_SUM, false);
+        if (first) EL_LAUNCH(SCALDPC_BP_PRODUCT_SUM, true); else EL_LAUNCH(SCALDPC_BP_PRODUCT_SUM, false);
     }
 #undef EL_LAUNCH
     LAUNCH_CHECK();
@@ -1523,7 +1562,7 @@ int iterate_group(scaldpc_bp *h, const TileState &st, int g0, int g, int max_ite
     const int skip = early ? 1 : 0;
     const u64 *synd_g = st.synd + (size_t)g0 * h->m;
     u64 *hard_g = st.hard + (size_t)g0 * h->n;
-    u64 *done_g = st.done + g0, *conv_g = st.conv + g0, *unsat_g = st.unsat + g0;
+    u64 *done_g = st.done + g0, *conv_g = st.conv + g0, *unsat_g = st.unsat + (size_t)g0 * parity_waves(h);
     int *iters_g = st.iters + (size_t)g0 * TW;
     float *post_g = st.post ? st.post + (size_t)g0 * h->n * TW : nullptr;
     *deferred = false;
@@ -1551,7 +1590,7 @@ int iterate_group(scaldpc_bp *h, const TileState &st, int g0, int g, int max_ite
             hipLaunchKernelGGL(k_parity<true>, dim3((h->m + 4 * ROWS_PER_WAVE - 1) / (4 * ROWS_PER_WAVE), g), dim3(256), 0, s, h->d_row_ptr, h->d_col_idx,
                                hard_g, h->m, h->n, const_cast<u64 *>(synd_g), unsat_g, (const u64 *)done_g);
             LAUNCH_CHECK();
-            hipLaunchKernelGGL(k_finalize, dim3(g), dim3(64), 0, s, it, early ? 1 : 0, done_g, conv_g, unsat_g, iters_g,
+            hipLaunchKernelGGL(k_finalize, dim3(g), dim3(64), 0, s, it, early ? 1 : 0, done_g, conv_g, unsat_g, parity_waves(h), iters_g,
                                h->d_remaining + it);
             LAUNCH_CHECK();
         }
@@ -1645,7 +1684,7 @@ int decode_level(scaldpc_bp *h, int lvl, const TileState &st, int batch, int T, 
         SC_TRY(dev_alloc(&L.hard, (size_t)T2 * h->n));
         SC_TRY(dev_alloc(&L.done, (size_t)T2));
         SC_TRY(dev_alloc(&L.conv, (size_t)T2));
-        SC_TRY(dev_alloc(&L.unsat, (size_t)T2));
+        SC_TRY(dev_alloc(&L.unsat, (size_t)T2 * parity_waves(h)));
         SC_TRY(dev_alloc(&L.iters, (size_t)T2 * TW));
         SC_TRY(dev_alloc(&L.ids, (size_t)T2 * TW));
         L.cap_tiles = T2;
@@ -1656,7 +1695,7 @@ int decode_level(scaldpc_bp *h, int lvl, const TileState &st, int batch, int T, 
     SC_HIP(hipMemcpyAsync(L.slot_of, slot_of.data(), sizeof(int) * slot_of.size(), hipMemcpyHostToDevice, s));
     hipLaunchKernelGGL(k_gather_planes, dim3((h->m + 63) / 64, T2), dim3(256), 0, s, st.synd, h->m, L.ids, L.synd);
     LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_init_state, dim3(T2), dim3(64), 0, s, batch2, max_iter, L.done, L.conv, L.unsat, L.iters);
+    hipLaunchKernelGGL(k_init_state, dim3(T2), dim3(64), 0, s, batch2, max_iter, L.done, L.conv, L.iters);
     LAUNCH_CHECK();
     SC_HIP(hipMemsetAsync(L.hard, 0, sizeof(u64) * (size_t)T2 * h->n, s));
     SC_HIP(hipStreamSynchronize(s));  // ids / slot_of are locals, and the level below reuses the stream
@@ -1679,8 +1718,7 @@ int decode_level(scaldpc_bp *h, int lvl, const TileState &st, int batch, int T, 
 int run_core(scaldpc_bp *h, int batch, int T, int G, int max_iter, int method, float alpha, bool early,
              bool want_post, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_init_state, dim3(T), dim3(64), 0, s, batch, max_iter, h->d_done, h->d_conv, h->d_unsat,
-                       h->d_iters);
+    hipLaunchKernelGGL(k_init_state, dim3(T), dim3(64), 0, s, batch, max_iter, h->d_done, h->d_conv, h->d_iters);
     LAUNCH_CHECK();
     SC_HIP(hipMemsetAsync(h->d_hard, 0, sizeof(u64) * (size_t)T * h->n, s));
     h->last_group = 0;
