@@ -1556,7 +1556,8 @@ struct TileState {
 // codewords are still running, and reports *deferred = true: those go to the compact pass.
 // el > 0: the group is ONE tile holding `el` codewords, decoded by the row-parallel kernels.
 int iterate_group(scaldpc_bp *h, const TileState &st, int g0, int g, int max_iter, int method, float alpha, bool early,
-                  int defer_after, hipStream_t s, bool *deferred, int el = 0, int real_codewords = 0)
+                  int defer_after, hipStream_t s, bool *deferred, int el = 0, int real_codewords = 0,
+                  int *poll_hint = nullptr)
 {
     const int poll_every = 4;
     const int skip = early ? 1 : 0;
@@ -1594,12 +1595,15 @@ int iterate_group(scaldpc_bp *h, const TileState &st, int g0, int g, int max_ite
                                h->d_remaining + it);
             LAUNCH_CHECK();
         }
-        const bool poll = it % poll_every == 0 || it == 1 || it == defer_after;
+        // a poll drains the queue (the GPU idles while the host turns around): skip the poll
+        // points at which the call's earlier groups saw no codeword finish yet
+        const bool poll = (it % poll_every == 0 || it == 1 || it == defer_after) && (!poll_hint || it >= *poll_hint);
         if (early && !last && poll) {
             SC_HIP(hipMemcpyAsync(h->h_remaining + it, h->d_remaining + it, sizeof(int), hipMemcpyDeviceToHost, s));
             SC_HIP(hipStreamSynchronize(s));
             const int rem = h->h_remaining[it];
             if (rem == 0) break;
+            if (poll_hint && rem >= real_codewords) *poll_hint = std::max(*poll_hint, it + 1);
             // from `defer_after` on, any poll point may hand the stragglers over, provided the
             // restart (it iterations redone) is cheap next to what is still ahead
             // ... and the stragglers really get cheaper: fewer tiles, or few enough for the
@@ -1643,11 +1647,12 @@ int decode_level(scaldpc_bp *h, int lvl, const TileState &st, int batch, int T, 
     }
     std::vector<char> deferred_tile(T, 0);
     bool any = false;
+    int poll_hint = 1;
     for (int g0 = 0; g0 < T; g0 += Gl) {
         const int g = std::min(Gl, T - g0);
         const int real = std::min(batch - g0 * TW, g * TW);
         bool d = false;
-        SC_TRY(iterate_group(h, st, g0, g, max_iter, method, alpha, early, defer_after, s, &d, el, real));
+        SC_TRY(iterate_group(h, st, g0, g, max_iter, method, alpha, early, defer_after, s, &d, el, real, &poll_hint));
         if (d) {
             any = true;
             for (int t = g0; t < g0 + g; t++) deferred_tile[t] = 1;
