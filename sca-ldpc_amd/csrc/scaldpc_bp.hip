@@ -822,23 +822,22 @@ __global__ __launch_bounds__(256) void k_var(Buckets bk, const int *__restrict__
 {
     const int lane = threadIdx.x & 63;
     const int tl = blockIdx.y;
+    // one 16-byte descriptor per WAVE of the launch: {column or -1 (padding of a bucket's last
+    // block), start in the re-laid edge list, degree, unroll bound of the bucket}: the wave's
+    // whole prologue is this one load (walking the bucket table first cost a chain of
+    // dependent scalar loads); `csc_edge` here is the edge list laid out in launch order
+    const int4 md = ((const int4 *)list)[(size_t)blockIdx.x * 4 + (threadIdx.x >> 6)];
     const u64 dn = done[tl];
     if (skip_done && dn == ~0ull) return;
-    int b = 0;
-    while (b + 1 < bk.nb && (int)blockIdx.x >= bk.blk[b + 1]) b++;
-    const int slot = ((int)blockIdx.x - bk.blk[b]) * 4 + (threadIdx.x >> 6);
-    if (slot >= bk.cnt[b]) return;
-    // one 16-byte descriptor per column in launch order: {column, start in the re-laid edge
-    // list, degree}; `csc_edge` here is the edge list laid out in that same order
-    const int4 md = ((const int4 *)list)[bk.off[b] + slot];
     const int v = rfl(md.x);
+    if (v < 0) return;
     const int cb = rfl(md.y);
     const int d = rfl(md.z);
     float *mt = msg + (size_t)tl * E * TW + lane;
     const int *ce = csc_edge + cb;
     const float pr = prior[v];
     float L = pr;
-    switch (bk.maxd[b]) {
+    switch (rfl(md.w)) {
         case 1: L = var_col<1>(mt, ce, d, pr); break;
         case 2: L = var_col<2>(mt, ce, d, pr); break;
         case 4: L = var_col<4>(mt, ce, d, pr); break;
@@ -1873,7 +1872,7 @@ int scaldpc_bp_create(int32_t m, int32_t n, int64_t nnz, const int32_t *row_ptr,
     };
     const size_t o_row_ptr = reserve((size_t)m + 1), o_col_idx = reserve((size_t)nnz), o_col_ptr = reserve((size_t)n + 1);
     const size_t o_csc_edge = reserve((size_t)nnz), o_var_list = reserve(hv.list.size());
-    const size_t o_var_meta = reserve(4 * hv.list.size() + 4), o_csc_list = reserve((size_t)nnz + 1);
+    const size_t o_var_meta = reserve((size_t)16 * hv.bk.blk[hv.bk.nb] + 4), o_csc_list = reserve((size_t)nnz + 1);
     const size_t o_row_list = reserve(hr.list.size());
     const size_t o_el_slots = reserve((size_t)el_waves * 128), o_el_winfo = reserve((size_t)el_waves * 2);
     const size_t o_prior = reserve((size_t)n);
@@ -1902,17 +1901,26 @@ int scaldpc_bp_create(int32_t m, int32_t n, int64_t nnz, const int32_t *row_ptr,
     TMARK("csc");
     std::copy(hv.list.begin(), hv.list.end(), host + o_var_list);
     std::copy(hr.list.begin(), hr.list.end(), host + o_row_list);
-    {  // k_var: one packed descriptor per column and the edge lists in launch order
+    {  // k_var: one packed descriptor per wave of the launch and the edge lists in launch order
         int *meta = host + o_var_meta, *relaid = host + o_csc_list;
         int pos = 0;
-        for (size_t i = 0; i < hv.list.size(); i++) {
-            const int v = hv.list[i], d = cdeg[v];
-            meta[4 * i + 0] = v;
-            meta[4 * i + 1] = pos;
-            meta[4 * i + 2] = d;
-            meta[4 * i + 3] = 0;
-            for (int k = 0; k < d; k++) relaid[pos + k] = csc_edge[(size_t)col_ptr[v] + k];
-            pos += d;
+        for (int b = 0; b < hv.bk.nb; b++) {
+            const int blocks = hv.bk.blk[b + 1] - hv.bk.blk[b];
+            for (int sl = 0; sl < blocks * 4; sl++) {
+                int *md = meta + 4 * ((size_t)hv.bk.blk[b] * 4 + sl);
+                if (sl >= hv.bk.cnt[b]) {
+                    md[0] = -1;
+                    md[1] = md[2] = md[3] = 0;
+                    continue;
+                }
+                const int v = hv.list[hv.bk.off[b] + sl], d = cdeg[v];
+                md[0] = v;
+                md[1] = pos;
+                md[2] = d;
+                md[3] = hv.bk.maxd[b];
+                for (int k = 0; k < d; k++) relaid[pos + k] = csc_edge[(size_t)col_ptr[v] + k];
+                pos += d;
+            }
         }
     }
     TMARK("meta");
