@@ -557,14 +557,14 @@ __global__ __launch_bounds__(256) void k_check_tanh(Buckets bk, const int *__res
 {
     const int lane = threadIdx.x & 63;
     const int tl = blockIdx.y;
+    // one descriptor per WAVE of the launch: {row or -1 (padding), first edge, degree, 0 = any-degree
+    // fallback}: a single load instead of bucket table -> row list -> row_ptr
+    const int4 md = ((const int4 *)list)[(size_t)blockIdx.x * 4 + (threadIdx.x >> 6)];
     if (skip_done && done[tl] == ~0ull) return;
-    int b = 0;
-    while (b + 1 < bk.nb && (int)blockIdx.x >= bk.blk[b + 1]) b++;
-    const int slot = ((int)blockIdx.x - bk.blk[b]) * 4 + (threadIdx.x >> 6);
-    if (slot >= bk.cnt[b]) return;
-    const int r = rfl(list[bk.off[b] + slot]);
-    const int e0 = rfl(row_ptr[r]);
-    const int deg = rfl(row_ptr[r + 1]) - e0;
+    const int r = rfl(md.x);
+    if (r < 0) return;
+    const int e0 = rfl(md.y);
+    const int deg = rfl(md.z);
     const size_t base = ((size_t)tl * E + e0) * TW + lane;
     float *p = msg + base;
     const unsigned sbit = (unsigned)(synd[(size_t)tl * m + r] >> lane) & 1u;
@@ -574,7 +574,7 @@ __global__ __launch_bounds__(256) void k_check_tanh(Buckets bk, const int *__res
         if constexpr (D <= CAP) check_tanh_row<D, FIRST>(p, sbit, prior, col_idx + e0);    \
         break;
 #define TR8(D) TR(D) TR(D + 1) TR(D + 2) TR(D + 3) TR(D + 4) TR(D + 5) TR(D + 6) TR(D + 7)
-    if (bk.maxd[b] == 0) {
+    if (rfl(md.w) == 0) {
         check_tanh_row_generic(p, scratch + base, deg, sbit);
     } else {
         switch (deg) {
@@ -1873,7 +1873,7 @@ int scaldpc_bp_create(int32_t m, int32_t n, int64_t nnz, const int32_t *row_ptr,
     const size_t o_row_ptr = reserve((size_t)m + 1), o_col_idx = reserve((size_t)nnz), o_col_ptr = reserve((size_t)n + 1);
     const size_t o_csc_edge = reserve((size_t)nnz), o_var_list = reserve(hv.list.size());
     const size_t o_var_meta = reserve((size_t)16 * hv.bk.blk[hv.bk.nb] + 4), o_csc_list = reserve((size_t)nnz + 1);
-    const size_t o_row_list = reserve(hr.list.size());
+    const size_t o_row_list = reserve((size_t)16 * hr.bk.blk[hr.bk.nb] + 4);
     const size_t o_el_slots = reserve((size_t)el_waves * 128), o_el_winfo = reserve((size_t)el_waves * 2);
     const size_t o_prior = reserve((size_t)n);
     if (total > stage.cap) {
@@ -1900,7 +1900,18 @@ int scaldpc_bp_create(int32_t m, int32_t n, int64_t nnz, const int32_t *row_ptr,
     }
     TMARK("csc");
     std::copy(hv.list.begin(), hv.list.end(), host + o_var_list);
-    std::copy(hr.list.begin(), hr.list.end(), host + o_row_list);
+    for (int b = 0; b < hr.bk.nb; b++) {  // k_check_tanh: one descriptor per wave of the launch
+        const int blocks = hr.bk.blk[b + 1] - hr.bk.blk[b];
+        for (int sl = 0; sl < blocks * 4; sl++) {
+            int *md = host + o_row_list + 4 * ((size_t)hr.bk.blk[b] * 4 + sl);
+            const bool pad = sl >= hr.bk.cnt[b];
+            const int r = pad ? -1 : hr.list[hr.bk.off[b] + sl];
+            md[0] = r;
+            md[1] = pad ? 0 : row_ptr[r];
+            md[2] = pad ? 0 : rdeg[r];
+            md[3] = hr.bk.maxd[b];
+        }
+    }
     {  // k_var: one packed descriptor per wave of the launch and the edge lists in launch order
         int *meta = host + o_var_meta, *relaid = host + o_csc_list;
         int pos = 0;
