@@ -45,6 +45,24 @@ def main():
         t4 = time.perf_counter()
         print(json.dumps({"new_decoder_ms": round((t1 - t0) * 1e3, 3), "first_decode_ms": round((t2 - t1) * 1e3, 3),
                           "second_decode_ms": round((t3 - t2) * 1e3, 3), "close_ms": round((t4 - t3) * 1e3, 3)}), flush=True)
+    # the attack loop's usual case while checks are still scarce: a decode that never converges
+    # runs all max_iter = 100 iterations WITH the per-iteration convergence test
+    rng = np.random.RandomState(0)
+    xbad = np.concatenate([np.zeros(N, np.uint8), rng.randint(0, 2, H.m).astype(np.uint8)])
+    for label, env in (("tiles", {"SCALDPC_PATH": "stream"}), ("row-parallel, 4 launches/iteration", {"SCALDPC_EL_FUSE": "0"}),
+                       ("row-parallel, 2 launches/iteration", {})):
+        for k in ("SCALDPC_PATH", "SCALDPC_EL_FUSE"):
+            os.environ.pop(k, None)
+        os.environ.update(env)
+        warm.decode(xbad)
+        t0 = time.perf_counter()
+        for _ in range(5):
+            warm.decode(xbad)
+        dt = (time.perf_counter() - t0) / 5
+        print(json.dumps({"non_converging_decode_100_iterations": label, "ms": round(dt * 1e3, 3), "iter": int(warm.iter),
+                          "converge": int(warm.converge)}), flush=True)
+    for k in ("SCALDPC_PATH", "SCALDPC_EL_FUSE"):
+        os.environ.pop(k, None)
     warm.close()
     for method in ("min_sum", "product_sum"):
         dec = bp.bp_decoder(H, max_iter=100, bp_method=method, channel_probs=probs)

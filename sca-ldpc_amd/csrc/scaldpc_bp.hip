@@ -899,7 +899,8 @@ template <int METHOD, bool FIRST>
 __global__ __launch_bounds__(256) void k_el_check(const int *__restrict__ row_ptr, const int *__restrict__ col_idx,
                                                   const float *__restrict__ prior, float *emsg,
                                                   const u64 *__restrict__ synd, const u64 *__restrict__ done,
-                                                  int skip_done, int m, long E, float alpha)
+                                                  int skip_done, int m, long E, float alpha,
+                                                  const u64 *__restrict__ hard, int *__restrict__ unsat_prev)
 {
     const int lane = threadIdx.x & 63;
     int r = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -909,12 +910,19 @@ __global__ __launch_bounds__(256) void k_el_check(const int *__restrict__ row_pt
     if (skip_done && ((done[0] >> c) & 1)) return;  // frozen codeword
     const int e0 = rfl(row_ptr[r]);
     const int deg = rfl(row_ptr[r + 1]) - e0;
-    if (deg == 0) return;
     const bool act = lane < deg;
+    const unsigned sbit = (unsigned)(synd[r] >> c) & 1u;
+    // Early-exit runs: the H e == s test of the PREVIOUS iteration's decisions rides on this
+    // pass (the wave has the row anyway), k_el_var latches the verdict: two launches per
+    // iteration instead of four.  A flag per codeword, set by any unsatisfied row.
+    if (unsat_prev) {
+        const unsigned hb = act ? (unsigned)(hard[col_idx[e0 + lane]] >> c) & 1u : 0u;
+        if ((((unsigned)__popcll(__ballot(hb != 0u)) & 1u) ^ sbit) && lane == 0) unsat_prev[c] = 1;
+    }
+    if (deg == 0) return;
     float *p = emsg + (size_t)c * E + e0 + lane;
     float x = 0.0f;
     if (act) x = FIRST ? prior[col_idx[e0 + lane]] : *p;
-    const unsigned sbit = (unsigned)(synd[r] >> c) & 1u;
     if (METHOD == SCALDPC_BP_MIN_SUM) {
         // the sequential form starts its running minima at FLT_MAX: |x| = inf never wins
         const float a = act ? fminf(fabsf(x), FLT_MAX) : FLT_MAX;
@@ -961,14 +969,33 @@ __global__ __launch_bounds__(256) void k_el_var(const int2 *__restrict__ slots, 
                                                 const int *__restrict__ cols, int nwaves,
                                                 const float *__restrict__ prior, float *emsg,
                                                 float *__restrict__ post, u64 *__restrict__ hard,
-                                                const u64 *__restrict__ done, int skip_done, long E, int write_out)
+                                                u64 *done, int skip_done, long E, int write_out,
+                                                const int *__restrict__ unsat_prev, int it_prev, u64 *conv,
+                                                int *__restrict__ iters, int *__restrict__ remaining_prev)
 {
     const int lane = threadIdx.x & 63;
     int w = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (w >= nwaves) return;
     w = rfl(w);
     const int c = blockIdx.y;
-    if (skip_done && ((done[0] >> c) & 1)) return;  // frozen codeword
+    const bool frozen = (done[0] >> c) & 1;
+    if (skip_done && frozen) return;  // frozen codeword
+    if (unsat_prev) {
+        // verdict of k_el_check's fused test: no unsatisfied row => the codeword converged at
+        // iteration it_prev; its outputs (written by the previous launch of this kernel) stay,
+        // the first wave of its launch row records the fact.  Every wave of the row takes the
+        // same branch: the flags are read-only here and `done` only gains this very bit.
+        const bool newly = !frozen && unsat_prev[c] == 0;
+        if (newly) {
+            if (w == 0 && lane == 0) {
+                atomicOr(done, 1ull << c);
+                atomicOr(conv, 1ull << c);
+                iters[c] = it_prev;
+            }
+            return;
+        }
+        if (w == 0 && lane == 0 && !frozen) atomicAdd(remaining_prev, 1);
+    }
     const int2 sl = slots[(size_t)w * 64 + lane];
     const int e = sl.x, start = sl.y & 63, pos = (sl.y >> 6) & 127, deg = (sl.y >> 13) & 127;
     const bool head = ((sl.y >> 20) & 1) && pos == 0;  // first lane of a column's segment
@@ -1253,6 +1280,8 @@ struct scaldpc_bp {
     // row-parallel path (a handful of codewords): per-codeword message / prefix arrays [codeword][edge]
     float *d_emsg = nullptr;
     size_t cap_el = 0;
+    int *d_el_unsat = nullptr;  // [iteration][64] "some row unsatisfied" flags of the fused early-exit loop
+    size_t cap_el_unsat = 0;
     int *d_el_slots = nullptr, *d_el_winfo = nullptr;  // k_el_var: columns packed into waves of 64 lane slots
     int el_waves = 0;
     int *d_graph = nullptr;  // ONE allocation behind every graph array above and d_prior (views into it)
@@ -1508,12 +1537,12 @@ int launch_var(scaldpc_bp *h, int G, float *post_g, u64 *hard_g, const u64 *done
 }
 
 int launch_el_check(scaldpc_bp *h, int method, float alpha, int nb, const u64 *synd_g, const u64 *done_g,
-                    int skip_done, hipStream_t s, bool first)
+                    int skip_done, hipStream_t s, bool first, const u64 *hard_g = nullptr, int *unsat_prev = nullptr)
 {
     dim3 grid((h->m + 3) / 4, nb);
 #define EL_LAUNCH(M, F)                                                                                             \
     hipLaunchKernelGGL((k_el_check<M, F>), grid, dim3(256), 0, s, h->d_row_ptr, h->d_col_idx, h->d_prior, h->d_emsg,  \
-                       synd_g, done_g, skip_done, h->m, h->E, alpha)
+                       synd_g, done_g, skip_done, h->m, h->E, alpha, hard_g, unsat_prev)
     if (method == SCALDPC_BP_MIN_SUM) {
         if (first) EL_LAUNCH(SCALDPC_BP_MIN_SUM, true); else EL_LAUNCH(SCALDPC_BP_MIN_SUM, false);
     } else {
@@ -1524,15 +1553,16 @@ int launch_el_check(scaldpc_bp *h, int method, float alpha, int nb, const u64 *s
     return 0;
 }
 
-int launch_el_var(scaldpc_bp *h, int nb, float *post_g, u64 *hard_g, const u64 *done_g, int skip_done, int write_out,
-                  hipStream_t s)
+int launch_el_var(scaldpc_bp *h, int nb, float *post_g, u64 *hard_g, u64 *done_g, int skip_done, int write_out,
+                  hipStream_t s, const int *unsat_prev = nullptr, int it_prev = 0, u64 *conv_g = nullptr,
+                  int *iters_g = nullptr, int *remaining_prev = nullptr)
 {
     // grid.x a multiple of 8: block x lands on the same XCD for every codeword row, so an XCD's L2
     // keeps its share of the slot table
     const unsigned gx = (unsigned)(((h->el_waves + 3) / 4 + 7) / 8 * 8);
     hipLaunchKernelGGL(k_el_var, dim3(gx, nb), dim3(256), 0, s, (const int2 *)h->d_el_slots, (const int2 *)h->d_el_winfo,
                        h->d_var_list, h->el_waves, h->d_prior, h->d_emsg, post_g, hard_g, done_g, skip_done, h->E,
-                       write_out);
+                       write_out, unsat_prev, it_prev, conv_g, iters_g, remaining_prev);
     LAUNCH_CHECK();
     return 0;
 }
@@ -1553,6 +1583,56 @@ struct TileState {
 // All iterations of the tile group [g0, g0+g) of `st`.  With defer_after > 0 the group
 // stops at the first poll point from that iteration on at which at most half of its
 // codewords are still running, and reports *deferred = true: those go to the compact pass.
+// Early-exit loop of the row-parallel path: two launches per iteration.  check(it) also tests
+// H e == s on the decisions of iteration it-1, var(it) latches the codewords that passed
+// (frozen at it-1) before it updates the others; the last iteration is followed by the
+// ordinary k_parity / k_finalize pair.  The host looks at "still running after it-1" one
+// iteration late, so a finished call enqueues one iteration of (skipped) launches more than
+// the four-launch form -- and half as many overall.
+int iterate_el_early(scaldpc_bp *h, int nb, int max_iter, int method, float alpha, const u64 *synd_g, u64 *hard_g,
+                     u64 *done_g, u64 *conv_g, u64 *unsat_g, int *iters_g, float *post_g, hipStream_t s)
+{
+    const size_t flags = ((size_t)max_iter + 2) * TW;
+    if (flags > h->cap_el_unsat || !h->d_el_unsat) {
+        dev_free(h->d_el_unsat);
+        h->cap_el_unsat = 0;
+        SC_TRY(dev_alloc(&h->d_el_unsat, flags));
+        h->cap_el_unsat = flags;
+    }
+    SC_HIP(hipMemsetAsync(h->d_el_unsat, 0, sizeof(int) * flags, s));
+    SC_HIP(hipMemsetAsync(h->d_remaining, 0, sizeof(int) * ((size_t)max_iter + 2), s));
+    const bool fused = fused_init(h, method);
+    if (!fused) {
+        hipLaunchKernelGGL(k_el_init, dim3((unsigned)((h->E + 255) / 256), nb), dim3(256), 0, s, h->d_col_idx, h->d_prior,
+                           h->d_emsg, h->E);
+        LAUNCH_CHECK();
+    }
+    for (int it = 1; it <= max_iter; it++) {
+        int *up = it > 1 ? h->d_el_unsat + (size_t)(it - 1) * TW : nullptr;
+        SC_TRY(launch_el_check(h, method, alpha_for(alpha, it), nb, synd_g, done_g, 1, s, fused && it == 1, hard_g, up));
+        SC_TRY(launch_el_var(h, nb, post_g, hard_g, done_g, 1, 1, s, up, it - 1, conv_g, iters_g, h->d_remaining + it - 1));
+        if (it == max_iter) {
+            hipLaunchKernelGGL(k_parity<true>, dim3((h->m + 4 * ROWS_PER_WAVE - 1) / (4 * ROWS_PER_WAVE), 1), dim3(256), 0,
+                               s, h->d_row_ptr, h->d_col_idx, hard_g, h->m, h->n, const_cast<u64 *>(synd_g), unsat_g,
+                               (const u64 *)done_g);
+            LAUNCH_CHECK();
+            hipLaunchKernelGGL(k_finalize, dim3(1), dim3(64), 0, s, it, 1, done_g, conv_g, unsat_g, parity_waves(h), iters_g,
+                               h->d_remaining + it);
+            LAUNCH_CHECK();
+            break;
+        }
+        // Poll sparsely: a poll drains the queue and costs about as much as an iteration here,
+        // while iterations enqueued for codewords that turn out to be finished return at once.
+        const int ip = it - 1;  // the iteration whose verdict var(it) just latched
+        if (ip == 1 || (ip >= 4 && (ip <= 16 ? ip % 4 == 0 : ip % 16 == 0))) {
+            SC_HIP(hipMemcpyAsync(h->h_remaining + ip, h->d_remaining + ip, sizeof(int), hipMemcpyDeviceToHost, s));
+            SC_HIP(hipStreamSynchronize(s));
+            if (h->h_remaining[ip] == 0) break;
+        }
+    }
+    return 0;
+}
+
 // el > 0: the group is ONE tile holding `el` codewords, decoded by the row-parallel kernels.
 int iterate_group(scaldpc_bp *h, const TileState &st, int g0, int g, int max_iter, int method, float alpha, bool early,
                   int defer_after, hipStream_t s, bool *deferred, int el = 0, int real_codewords = 0,
@@ -1566,6 +1646,8 @@ int iterate_group(scaldpc_bp *h, const TileState &st, int g0, int g, int max_ite
     int *iters_g = st.iters + (size_t)g0 * TW;
     float *post_g = st.post ? st.post + (size_t)g0 * h->n * TW : nullptr;
     *deferred = false;
+    if (el && early && !(getenv("SCALDPC_EL_FUSE") && !strcmp(getenv("SCALDPC_EL_FUSE"), "0")))
+        return iterate_el_early(h, el, max_iter, method, alpha, synd_g, hard_g, done_g, conv_g, unsat_g, iters_g, post_g, s);
     const bool fused = fused_init(h, method);
     if (h->E && !fused) {
         if (el)
@@ -2397,7 +2479,7 @@ void scaldpc_bp_destroy(scaldpc_bp *h)
         dev_free(L.synd); dev_free(L.hard); dev_free(L.done); dev_free(L.conv); dev_free(L.unsat);
         dev_free(L.iters); dev_free(L.ids); dev_free(L.slot_of); dev_free(L.post);
     }
-    dev_free(h->d_emsg);
+    dev_free(h->d_emsg); dev_free(h->d_el_unsat);
     dev_free(h->d_thr); dev_free(h->d_mc); dev_free(h->d_diff); dev_free(h->d_ylist); dev_free(h->d_succ);
     CacheBypass guard(h->async_used);
     cached_free(h->h_remaining);

@@ -287,14 +287,19 @@ def test_row_parallel_path_is_taken_and_agrees_with_tiles(oracle, method, monkey
         for x in (synd[:nb], msg[:nb]):
             for early in (True, False):
                 out = {}
-                for path in ("edge", "stream"):
-                    monkeypatch.setenv("SCALDPC_PATH", path)
+                # "edge4": the four-launch form of the early-exit loop (convergence test as separate
+                # kernels) instead of the fused two-launch form
+                for path in ("edge", "edge4", "stream"):
+                    monkeypatch.setenv("SCALDPC_PATH", path.rstrip("4"))
+                    monkeypatch.setenv("SCALDPC_EL_FUSE", "0" if path == "edge4" else "1")
                     dec = bp.bp_decoder(H, max_iter=30, bp_method=method, channel_probs=probs)
                     out[path] = dec.decode_batch(x, early_exit=early, want_llr=True)
-                    assert dec.last_row_parallel() == (nb if path == "edge" else 0)
+                    assert dec.last_row_parallel() == (nb if path != "stream" else 0)
                     dec.close()
                 for k in ("bits", "llr", "iters", "converged"):
                     assert np.array_equal(out["edge"][k], out["stream"][k]), (nb, early, k)
+                    assert np.array_equal(out["edge4"][k], out["stream"][k]), (nb, early, k)
+    monkeypatch.delenv("SCALDPC_EL_FUSE")
     ref = oracle.bp_decode_batch(H, probs, msg[:64], 1, 30, ORACLE_METHOD[method], dtype="f32", threads=8,
                                  early_exit=False)
     compare(out["edge"], ref, method)  # nb = 64, received words, fixed iterations
