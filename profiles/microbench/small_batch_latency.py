@@ -64,6 +64,25 @@ def main():
     for k in ("SCALDPC_PATH", "SCALDPC_EL_FUSE"):
         os.environ.pop(k, None)
     warm.close()
+    # ... and the whole attack-loop step through the build's driver: 4000 accumulated checks,
+    # sparse graph assembly in Python + new decoder + decode + statistics (hqc.py:661-759)
+    D = importlib.import_module("sca-ldpc_amd.driver")
+    acc = D.HqcCheckAccumulator(N, rows["N17669_W50_s0"], omega)
+    rs = np.random.RandomState(5)
+    y = np.sort(rs.choice(N, omega, replace=False))
+    yv = np.zeros(N, np.uint8); yv[y] = 1
+    for b in rs.permutation(N)[:4000]:
+        sup = (int(b) - acc.k) % N
+        acc.add_check(int(b), int(yv[sup].sum() & 1), 0.95)
+    acc.decode(list(y))
+    for rep in range(3):
+        t0 = time.perf_counter()
+        g = acc.graph()
+        t1 = time.perf_counter()
+        ok = acc.decode(list(y))
+        t2 = time.perf_counter()
+        print(json.dumps({"accumulator_graph_ms": round((t1 - t0) * 1e3, 3), "accumulator_decode_total_ms": round((t2 - t1) * 1e3, 3),
+                          "success": bool(ok)}), flush=True)
     for method in ("min_sum", "product_sum"):
         dec = bp.bp_decoder(H, max_iter=100, bp_method=method, channel_probs=probs)
         trials = dec.mc_hqc_run(64, omega=omega, eps=eps, seed=3, want_inputs=True)

@@ -262,7 +262,10 @@ class HqcCheckAccumulator:
         R = len(self._rows)
         W = self.k.size
         rows = np.repeat(np.arange(R), W + 1)
-        cols = np.concatenate([np.concatenate([r, [self.N + i]]) for i, r in enumerate(self._rows)]) if R else np.zeros(0, np.int64)
+        if R:  # each row: its W sorted circulant positions (< N), then its identity column N + i -- already CSR order
+            cols = np.concatenate([np.stack(self._rows), self.N + np.arange(R, dtype=np.int64)[:, None]], axis=1).ravel()
+        else:
+            cols = np.zeros(0, np.int64)
         return TannerGraph(R, self.N + R, rows, cols)
 
     def decode(self, y_sparse):

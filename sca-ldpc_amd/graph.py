@@ -23,7 +23,7 @@ import numpy as np
 
 
 class TannerGraph:
-    __slots__ = ("m", "n", "nnz", "row_ptr", "col_idx", "val", "col_ptr", "csc_edge", "csc_row")
+    __slots__ = ("m", "n", "nnz", "row_ptr", "col_idx", "val", "_csc")
 
     def __init__(self, m, n, rows, cols, vals=None):
         rows = np.asarray(rows, dtype=np.int64)
@@ -35,13 +35,21 @@ class TannerGraph:
         if vals is None:
             vals = np.ones(rows.size, dtype=np.int8)
         vals = np.asarray(vals, dtype=np.int8)
-        # CSR order: by row, then column
-        order = np.lexsort((cols, rows))
-        rows, cols, vals = rows[order], cols[order], vals[order]
+        # CSR order: by row, then column.  Callers on the attack loop's critical path (one graph per
+        # decode, hqc.py:680) hand the entries over already in that order: one vectorised check
+        # instead of a 200 000-entry lexsort.
         if rows.size > 1:
-            dup = (rows[1:] == rows[:-1]) & (cols[1:] == cols[:-1])
-            if dup.any():
-                raise ValueError("duplicate edges in parity-check matrix")
+            dr = np.diff(rows)
+            in_order = bool(((dr > 0) | ((dr == 0) & (np.diff(cols) > 0))).all())
+        else:
+            in_order = True
+        if not in_order:
+            order = np.lexsort((cols, rows))
+            rows, cols, vals = rows[order], cols[order], vals[order]
+            if rows.size > 1:
+                dup = (rows[1:] == rows[:-1]) & (cols[1:] == cols[:-1])
+                if dup.any():
+                    raise ValueError("duplicate edges in parity-check matrix")
         self.m = int(m)
         self.n = int(n)
         self.nnz = int(rows.size)
@@ -49,12 +57,28 @@ class TannerGraph:
         np.cumsum(np.bincount(rows, minlength=m), out=self.row_ptr[1:])
         self.col_idx = cols.astype(np.int32)
         self.val = vals
-        # CSC permutation: by column, then row (stable on the CSR order)
-        corder = np.lexsort((rows, cols))
-        self.col_ptr = np.zeros(n + 1, dtype=np.int32)
-        np.cumsum(np.bincount(cols, minlength=n), out=self.col_ptr[1:])
-        self.csc_edge = corder.astype(np.int32)
-        self.csc_row = rows[corder].astype(np.int32)
+        self._csc = None  # built on first use: the HIP library derives its own from the CSR arrays
+
+    def _build_csc(self):
+        # CSC permutation: by column, then row (a stable sort of the CSR order by column)
+        rows = np.repeat(np.arange(self.m, dtype=np.int64), np.diff(self.row_ptr))
+        corder = np.argsort(self.col_idx, kind="stable")
+        col_ptr = np.zeros(self.n + 1, dtype=np.int32)
+        np.cumsum(np.bincount(self.col_idx, minlength=self.n), out=col_ptr[1:])
+        self._csc = (col_ptr, corder.astype(np.int32), rows[corder].astype(np.int32))
+        return self._csc
+
+    @property
+    def col_ptr(self):
+        return (self._csc or self._build_csc())[0]
+
+    @property
+    def csc_edge(self):
+        return (self._csc or self._build_csc())[1]
+
+    @property
+    def csc_row(self):
+        return (self._csc or self._build_csc())[2]
 
     # -- constructors -------------------------------------------------------
     @classmethod
