@@ -39,6 +39,10 @@ WORKLOADS = {
     # BASELINE config 5: Monte-Carlo sweep, trials generated/decoded/compared on the device,
     # product_sum, early exit, max_iter 100 (hqc.py:696); --trials = whole-job trial count
     "hqc128_mc": ("hqc128", "N17669_W50_s0", "product_sum", 100),
+    # BASELINE config 4: q-ary (Q = 3) min-sum, the reference's DecoderN450R150V3C7B1 on its doctest
+    # H (150 x 450, decode.py:192-209), 5 iterations, --batch codewords (1024) per call, host pmf
+    # arrays in and symbols out as the PyO3 class takes them.  ALU-bound: no HBM roofline claim.
+    "qary_config4": (None, None, "qary_min_sum", 5),
 }
 
 
@@ -86,6 +90,8 @@ def main():
     lib.check(lib.load().scaldpc_set_device(local))
 
     hqc, key, method, iters = WORKLOADS[args.workload]
+    if args.workload == "qary_config4":
+        return qary_config4(args, S, rank, world, dist, backend, local, iters)
     rows = json.load(open(os.path.join(ROOT, "tests", "golden", "hqc_first_rows.json")))
     H, Hin, _ = S.codes.hqc_bench_graph(hqc, rows[key])
     N, omega = S.codes.HQC_PARAMS[hqc]
@@ -217,6 +223,53 @@ def main():
             out["cpu_baseline"] = cpu_baseline(H, probs, msg, iters, method, E, args.cpu_seconds)
         print(json.dumps(out), flush=True)
     dec.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def qary_config4(args, S, rank, world, dist, backend, local, iters):
+    """BASELINE config 4 through the simulate_rs-shaped class: `--steps` calls of min_sum_batch
+    on `--batch` (default here: 1024) codewords per rank; value = symbol-edge message updates / s
+    (2 * E * batch * iterations per call), plus ms per call."""
+    import torch
+
+    qary = importlib.import_module("sca-ldpc_amd.qary")
+    gens = json.load(open(os.path.join(ROOT, "tests", "golden", "generators.json")))
+    g = S.TannerGraph.from_coo(gens["regular_identity_300_150_3_6_s1"])
+    batch = 1024 if args.batch == 4096 else args.batch
+    rng = np.random.RandomState(7 + rank)
+    p = 1 / 3
+    good, bad = np.array([p, 1.75 * p, 0.25 * p]), np.array([p, 0.25 * p, 1.75 * p])  # decode.py:232-237
+    mask = rng.rand(batch, g.n) < 0.005
+    pmf = np.where(mask[:, :, None], bad, good).astype(np.float32)
+    dec = qary.decoder_class("DecoderN450R150V3C7B1")(g.to_dense(np.int8), iters)
+    for _ in range(max(1, args.warmup)):
+        out = dec.min_sum_batch(pmf)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = dec.min_sum_batch(pmf)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    if rank == 0:
+        print(json.dumps({
+            "metric": "edge_message_updates_per_s", "value": 2.0 * g.nnz * batch * iters * args.steps * world / dt,
+            "unit": "directed symbol-edge message updates/s", "n_gpus": world, "steps": args.steps, "warmup": max(1, args.warmup),
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"q-ary min-sum DecoderN450R150V3C7B1 (150x450, E={g.nnz}, Q=3), {iters} iterations, "
+                                   f"batch {batch}/GPU, host pmf in / symbols out (PCIe and the host-side probability->LLR "
+                                   f"conversion included)"},
+            "codewords_per_s": batch * args.steps * world / dt, "all_zero_rate": float((out == 0).all(axis=1).mean()),
+        }), flush=True)
     if world > 1:
         dist.destroy_process_group()
 

@@ -582,6 +582,8 @@ struct scaldpc_qary {
     signed char *d_hard = nullptr, *d_out = nullptr;
     size_t cap_pmf = 0, cap_pmf2 = 0, cap_out = 0;
     int *d_err = nullptr;
+    float *h_llr = nullptr;  // pinned staging of the host-side probability -> LLR conversion
+    size_t cap_h_llr = 0;
     hipStream_t own_stream = nullptr;
     std::mutex mu;
 };
@@ -697,7 +699,7 @@ int growq(T **p, size_t *cap, size_t need)
 // decoder.rs:668-692 on the host with glibc logf -- bit-identical to the oracle (and to what
 // the reference's f32::ln gives on the same platform).  One logf per symbol is the dominant
 // host cost of a large batch, so codewords are split over host threads.
-int host_into_llr(const float *pmf, int batch, int nv, int Q, long Bp, long row0, std::vector<float> &llr)
+int host_into_llr(const float *pmf, int batch, int nv, int Q, long Bp, long row0, float *llr)
 {
     const size_t work = (size_t)batch * nv * Q;
     int nthreads = 1;
@@ -727,13 +729,14 @@ int host_into_llr(const float *pmf, int batch, int nv, int Q, long Bp, long row0
                     }
                     mx[i] = m_;
                     if ((!have || !(sum < 1.0f + 0.001f) || !(sum > 1.0f - 0.001f)) &&
-                        (bad_b[tid] < 0 || b < bad_b[tid])) {
+                        (bad_b[tid] < 0 || b < bad_b[tid] || (b == bad_b[tid] && v < bad_v[tid]))) {
                         bad_b[tid] = b; bad_v[tid] = v; bad_kind[tid] = have ? 2 : 1; bad_sum[tid] = sum;
                     }
                 }
                 for (int q = 0; q < Q; q++) {
-                    float *dst = llr.data() + ((size_t)(row0 + (long)v * Q + q)) * Bp + b0;
+                    float *dst = llr + ((size_t)(row0 + (long)v * Q + q)) * Bp + b0;
                     for (int i = 0; i < nb; i++) dst[i] = logf(mx[i] / pmf[((size_t)(b0 + i) * nv + v) * Q + q]);
+                    for (int i = nb; i < 64; i++) dst[i] = 0.0f;  // padding lanes: all-equal messages
                 }
             }
         }
@@ -747,7 +750,8 @@ int host_into_llr(const float *pmf, int batch, int nv, int Q, long Bp, long row0
     }
     int first = -1;
     for (int t = 0; t < nthreads; t++)
-        if (bad_b[t] >= 0 && (first < 0 || bad_b[t] < bad_b[first])) first = t;
+        if (bad_b[t] >= 0 && (first < 0 || bad_b[t] < bad_b[first] || (bad_b[t] == bad_b[first] && bad_v[t] < bad_v[first])))
+            first = t;
     if (first >= 0) {
         if (bad_kind[first] == 1)
             return fail(SCALDPC_EPMF, "No maximum probability found (codeword %d, variable %d)", bad_b[first], bad_v[first]);
@@ -778,11 +782,19 @@ int qary_run(scaldpc_qary *h, const float *pmf_b, const float *pmf_s, int batch,
     SC_HIP(hipMemsetAsync(h->d_err, 0, sizeof(int), s));
     const int TB = 64;
     if (!dev_io) {
-        std::vector<float> llr((size_t)h->llr_rows * Bp, 0.0f);  // padding lanes: all-equal messages
-        SC_TRY(host_into_llr(pmf_b, batch, BV, h->Q, Bp, 0, llr));
-        if (h->special) SC_TRY(host_into_llr(pmf_s, batch, h->R, h->QS, Bp, (long)BV * h->Q, llr));
-        SC_HIP(hipMemcpyAsync(h->d_llr, llr.data(), llr.size() * sizeof(float), hipMemcpyHostToDevice, s));
-        SC_HIP(hipStreamSynchronize(s));  // llr is a local
+        // pinned staging buffer kept by the handle: a fresh 5 MB vector per call cost more in page
+        // faults and the pageable copy than the conversion itself
+        const size_t need = (size_t)h->llr_rows * Bp;
+        if (need > h->cap_h_llr) {
+            cached_free(h->h_llr);
+            h->h_llr = nullptr;
+            h->cap_h_llr = 0;
+            SC_TRY(cached_alloc((void **)&h->h_llr, need * sizeof(float), true));
+            h->cap_h_llr = need;
+        }
+        SC_TRY(host_into_llr(pmf_b, batch, BV, h->Q, Bp, 0, h->h_llr));
+        if (h->special) SC_TRY(host_into_llr(pmf_s, batch, h->R, h->QS, Bp, (long)BV * h->Q, h->h_llr));
+        SC_HIP(hipMemcpyAsync(h->d_llr, h->h_llr, need * sizeof(float), hipMemcpyHostToDevice, s));
     } else {
         hipLaunchKernelGGL(k_q_into_llr, dim3(BV, Bp / TB), dim3(TB), 0, s, pmf_b, BV, h->Q, batch, Bp, h->d_llr,
                            h->d_err);
@@ -903,6 +915,7 @@ void scaldpc_qary_destroy(scaldpc_qary *h)
     dev_free(h->d_row_ptr); dev_free(h->d_col_ptr); dev_free(h->d_csc_edge); dev_free(h->d_edge_var);
     dev_free(h->d_edge_h); dev_free(h->d_var_q); dev_free(h->d_var_off); dev_free(h->d_msg); dev_free(h->d_llr);
     dev_free(h->d_pmf); dev_free(h->d_pmf2); dev_free(h->d_hard); dev_free(h->d_out); dev_free(h->d_err);
+    cached_free(h->h_llr);
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
     delete h;
 }
