@@ -107,11 +107,17 @@ int scaldpc_bp_decode_batch(scaldpc_bp *h, const uint8_t *in, int32_t input_kind
                             void *stream, uint8_t *out_bits, float *out_llr, int32_t *out_iters,
                             uint8_t *out_conv);
 /*
- * Measurement aid for bench.py: on the message state left by the last decode, run
- * `iters` back-to-back launches of the check kernel and then of the variable kernel
- * of `method` over one tile group, each series bracketed by HIP events on the launch
- * stream.  ms[0] / ms[1] = total ms of each series, launches[0..1] = launches in it,
- * launches[2] = codewords swept per launch.  (ms: float[2], launches: int32[3].)
+ * Measurement aid for bench.py: on the message state left by the last (fixed-iteration)
+ * decode, run `iters` back-to-back launches of the check kernel and of the variable kernel of
+ * `method`, each series bracketed by HIP events on its launch stream.
+ *   ms[0] / ms[1]   total ms of the check / variable series          (float[2])
+ *   launches[0..1]  launches in each series                           (int32[6])
+ *   launches[2]     codewords swept per check launch
+ *   launches[3]     lanes: 1 = the series ran one after the other over the whole tile group;
+ *                   2 = the decode's two-stream schedule: the check series over the first
+ *                   lane's tiles and the variable series over the second lane's tiles ran
+ *                   concurrently, as they do in a decode's steady state
+ *   launches[4]     codewords swept per variable launch;  launches[5] reserved (0)
  */
 int scaldpc_bp_time_kernels(scaldpc_bp *h, int32_t iters, int32_t method, float alpha, void *stream,
                             float *ms, int32_t *launches);

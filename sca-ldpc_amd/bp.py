@@ -191,15 +191,17 @@ class BpDecoder:
 
     def time_kernels(self, iters, stream=0):
         """HIP-event timing of the check / variable kernels on the last decode's state.
-        Returns dict(ms_check, ms_var, launches_check, launches_var, codewords)."""
+        Returns dict(ms_check, ms_var, launches_check, launches_var, codewords per check launch, lanes);
+        lanes = 2: the two series ran concurrently on the two streams of the decode's schedule."""
         ms = (C.c_float * 2)()
-        ln = (C.c_int32 * 3)()
+        ln = (C.c_int32 * 6)()
         _lib.check(
             self._lib.scaldpc_bp_time_kernels(
                 self._h, iters, self._method, self.ms_scaling_factor, C.c_void_p(stream or None), ms, ln
             )
         )
-        return {"ms_check": ms[0], "ms_var": ms[1], "launches_check": ln[0], "launches_var": ln[1], "codewords": ln[2]}
+        return {"ms_check": ms[0], "ms_var": ms[1], "launches_check": ln[0], "launches_var": ln[1], "codewords": ln[2],
+                "lanes": ln[3], "codewords_var": ln[4]}
 
     # -- Monte-Carlo helpers on the device (K6) --------------------------------------
     def mc_fer_run(self, runs, seed, first_trial=0, max_iter=None, early_exit=True, want_errors=False):

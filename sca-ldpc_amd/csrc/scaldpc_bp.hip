@@ -1289,6 +1289,8 @@ struct scaldpc_bp {
     int identity_from = -1;  // n - m if the last m columns of H are I_m (H = [Hin | I]), else -1
     hipStream_t own_stream = nullptr;
     int device = 0;  // the device the handle (and its stream) was created on
+    hipStream_t aux_stream[4] = {};  // further lanes of the fixed-iteration schedule (iterate_fixed_split)
+    hipEvent_t ev_join[4] = {}, ev_phase[4] = {};
     // Set by the first SCALDPC_F_ASYNC call and never cleared: work may be in flight when a later call
     // (or destroy) releases a buffer, so this handle's blocks go back through hipFree (which
     // waits for the device) instead of being parked for immediate reuse.
@@ -1486,13 +1488,15 @@ bool fused_init(const scaldpc_bp *h, int method)
 }
 
 int launch_check(scaldpc_bp *h, int method, float alpha, int G, const u64 *synd_g, const u64 *done_g, int skip_done,
-                 hipStream_t s, bool first = false)
+                 hipStream_t s, bool first = false, int tile0 = 0)
 {
     if (h->E == 0) return 0;
+    float *const msg0 = h->d_msg + (size_t)tile0 * h->E * TW;  // tile0: first tile of a sub-group inside the group's array
+    float *const scr0 = h->d_scratch ? h->d_scratch + (size_t)tile0 * h->E * TW : nullptr;
     if (method == SCALDPC_BP_MIN_SUM) {
         dim3 grid((h->m + 3) / 4, G);
 #define MS_LAUNCH(W, F)                                                                                              \
-    hipLaunchKernelGGL((k_check_minsum<W, F>), grid, dim3(256), 0, s, h->d_row_ptr, h->d_msg, synd_g, done_g, skip_done, \
+    hipLaunchKernelGGL((k_check_minsum<W, F>), grid, dim3(256), 0, s, h->d_row_ptr, msg0, synd_g, done_g, skip_done, \
                        h->m, h->E, alpha, h->d_col_idx, h->d_prior)
         if (h->max_row_deg <= ROW_CAP) {
             if (first) MS_LAUNCH(false, true); else MS_LAUNCH(false, false);
@@ -1503,8 +1507,8 @@ int launch_check(scaldpc_bp *h, int method, float alpha, int G, const u64 *synd_
     } else {
         dim3 grid(h->row_bk.blk[h->row_bk.nb], G);
 #define TANH_LAUNCH(CAP, F)                                                                                         \
-    hipLaunchKernelGGL((k_check_tanh<CAP, F>), grid, dim3(256), 0, s, h->row_bk, h->d_row_list, h->d_row_ptr, h->d_msg, \
-                       h->d_scratch, synd_g, done_g, skip_done, h->m, h->E, h->d_col_idx, h->d_prior)
+    hipLaunchKernelGGL((k_check_tanh<CAP, F>), grid, dim3(256), 0, s, h->row_bk, h->d_row_list, h->d_row_ptr, msg0, \
+                       scr0, synd_g, done_g, skip_done, h->m, h->E, h->d_col_idx, h->d_prior)
         if (h->max_row_deg <= 16) {
             if (first) TANH_LAUNCH(16, true); else TANH_LAUNCH(16, false);
         } else if (h->max_row_deg <= 32) {
@@ -1519,12 +1523,14 @@ int launch_check(scaldpc_bp *h, int method, float alpha, int G, const u64 *synd_
 }
 
 int launch_var(scaldpc_bp *h, int G, float *post_g, u64 *hard_g, const u64 *done_g, int skip_done, int write_out,
-               hipStream_t s)
+               hipStream_t s, int tile0 = 0)
 {
     dim3 grid(h->var_bk.blk[h->var_bk.nb], G);
+    float *const msg0 = h->d_msg + (size_t)tile0 * h->E * TW;
+    float *const scr0 = h->d_scratch ? h->d_scratch + (size_t)tile0 * h->E * TW : nullptr;
 #define VAR_LAUNCH(CAP)                                                                                             \
     hipLaunchKernelGGL(k_var<CAP>, grid, dim3(256), 0, s, h->var_bk, h->d_var_meta, h->d_col_ptr, h->d_csc_list,      \
-                       h->d_prior, h->d_msg, h->d_scratch, post_g, hard_g, done_g, skip_done, h->n, h->E, write_out)
+                       h->d_prior, msg0, scr0, post_g, hard_g, done_g, skip_done, h->n, h->E, write_out)
     if (h->max_col_deg <= 16)
         VAR_LAUNCH(16);
     else if (h->max_col_deg <= 32)
@@ -1633,6 +1639,82 @@ int iterate_el_early(scaldpc_bp *h, int nb, int max_iter, int method, float alph
     return 0;
 }
 
+// Fixed-iteration schedule of one tile group on SEVERAL streams ("lanes"): the group's tiles are
+// split into lanes whose launch sequences (independent: a pass depends only on the previous
+// pass over the same tiles) run one kernel out of phase, so that while one lane drains the tail
+// of its kernel another lane's kernel fills the machine.  Same kernels, same cache footprint,
+// same results.
+constexpr int MAX_LANES = 4;
+// measured on the HQC-128 bench (4-tile groups, ms per 4096-codeword step): 1 lane 104.0,
+// 2 lanes 98.5, 3 lanes 101.3, 4 lanes 106.8 -- two kernels in flight fill each other's tails,
+// more only shrink the launches.  SCALDPC_SPLIT=n overrides (1 = single stream).
+int fixed_lanes(const scaldpc_bp *h, int g)
+{
+    int nl = 2;
+    if (const char *e = getenv("SCALDPC_SPLIT")) nl = atoi(e);
+    if (h->E == 0) return 1;
+    return std::max(1, std::min(std::min(nl, g), MAX_LANES));
+}
+int iterate_fixed_split(scaldpc_bp *h, const TileState &st, int g0, int g, int max_iter, int method, float alpha,
+                        hipStream_t s, int nl)
+{
+    nl = std::min(std::min(nl, g), MAX_LANES);
+    for (int k = 1; k < nl; k++)
+        if (!h->aux_stream[k]) {
+            int dev = 0;
+            SC_TRY(stream_acquire(&h->aux_stream[k], &dev));
+            SC_HIP(hipEventCreateWithFlags(&h->ev_join[k], hipEventDisableTiming));
+            SC_HIP(hipEventCreateWithFlags(&h->ev_phase[k], hipEventDisableTiming));
+        }
+    hipStream_t lane[MAX_LANES];
+    int gs[MAX_LANES], t0[MAX_LANES];
+    for (int k = 0, t = 0; k < nl; k++) {
+        lane[k] = k ? h->aux_stream[k] : s;
+        gs[k] = g / nl + (k < g % nl ? 1 : 0);
+        t0[k] = t;
+        t += gs[k];
+    }
+    const int pw = parity_waves(h);
+    const bool fused = fused_init(h, method);
+    if (!fused) {
+        hipLaunchKernelGGL(k_init_msg, dim3((unsigned)((h->E + 3) / 4), g), dim3(256), 0, s, h->d_col_idx, h->d_prior,
+                           h->d_msg, h->E);
+        LAUNCH_CHECK();
+    }
+    for (int it = 1; it <= max_iter; it++) {
+        const bool last = it == max_iter;
+        for (int k = 0; k < nl; k++) {
+            const int ta = g0 + t0[k];
+            SC_TRY(launch_check(h, method, alpha_for(alpha, it), gs[k], st.synd + (size_t)ta * h->m, st.done + ta, 0, lane[k],
+                                fused && it == 1, t0[k]));
+            if (it == 1 && k + 1 < nl) {  // the next lane starts one kernel late (and after everything before the fork)
+                SC_HIP(hipEventRecord(h->ev_phase[k + 1], lane[k]));
+                SC_HIP(hipStreamWaitEvent(lane[k + 1], h->ev_phase[k + 1], 0));
+            }
+        }
+        for (int k = 0; k < nl; k++) {
+            const int ta = g0 + t0[k];
+            SC_TRY(launch_var(h, gs[k], st.post ? st.post + (size_t)ta * h->n * TW : nullptr, st.hard + (size_t)ta * h->n,
+                              st.done + ta, 0, last ? 1 : 0, lane[k], t0[k]));
+            if (last) {
+                hipLaunchKernelGGL(k_parity<true>, dim3((h->m + 4 * ROWS_PER_WAVE - 1) / (4 * ROWS_PER_WAVE), gs[k]), dim3(256),
+                                   0, lane[k], h->d_row_ptr, h->d_col_idx, st.hard + (size_t)ta * h->n, h->m, h->n,
+                                   const_cast<u64 *>(st.synd + (size_t)ta * h->m), st.unsat + (size_t)ta * pw,
+                                   (const u64 *)(st.done + ta));
+                LAUNCH_CHECK();
+                hipLaunchKernelGGL(k_finalize, dim3(gs[k]), dim3(64), 0, lane[k], it, 0, st.done + ta, st.conv + ta,
+                                   st.unsat + (size_t)ta * pw, pw, st.iters + (size_t)ta * TW, h->d_remaining + it);
+                LAUNCH_CHECK();
+            }
+        }
+    }
+    for (int k = 1; k < nl; k++) {
+        SC_HIP(hipEventRecord(h->ev_join[k], lane[k]));
+        SC_HIP(hipStreamWaitEvent(s, h->ev_join[k], 0));
+    }
+    return 0;
+}
+
 // el > 0: the group is ONE tile holding `el` codewords, decoded by the row-parallel kernels.
 int iterate_group(scaldpc_bp *h, const TileState &st, int g0, int g, int max_iter, int method, float alpha, bool early,
                   int defer_after, hipStream_t s, bool *deferred, int el = 0, int real_codewords = 0,
@@ -1646,6 +1728,8 @@ int iterate_group(scaldpc_bp *h, const TileState &st, int g0, int g, int max_ite
     int *iters_g = st.iters + (size_t)g0 * TW;
     float *post_g = st.post ? st.post + (size_t)g0 * h->n * TW : nullptr;
     *deferred = false;
+    if (!el && !early && fixed_lanes(h, g) >= 2)
+        return iterate_fixed_split(h, st, g0, g, max_iter, method, alpha, s, fixed_lanes(h, g));
     if (el && early && !(getenv("SCALDPC_EL_FUSE") && !strcmp(getenv("SCALDPC_EL_FUSE"), "0")))
         return iterate_el_early(h, el, max_iter, method, alpha, synd_g, hard_g, done_g, conv_g, unsat_g, iters_g, post_g, s);
     const bool fused = fused_init(h, method);
@@ -2442,25 +2526,92 @@ int scaldpc_bp_time_kernels(scaldpc_bp *h, int32_t iters, int32_t method, float 
     if (h->last_group <= 0) return fail(SCALDPC_EINVAL, "no previous decode to time");
     hipStream_t s = stream ? (hipStream_t)stream : h->own_stream;
     const int g = h->last_group;
+    const int nl = std::min(fixed_lanes(h, g), 2);
     // `iters` back-to-back launches of each kernel between two events: the event
     // overhead (a few us, comparable to a 65 us launch) is amortised, what remains is
     // the kernel plus the ~1.5 us dependent-launch gap it also pays in a real decode.
-    std::vector<hipEvent_t> ev(4);
+    // Two-lane schedule (what a fixed-iteration decode runs): the decode's own launch pattern --
+    // each lane alternates check and variable launches over its half of the group, the second
+    // lane one kernel out of phase -- with an event after EVERY launch; a launch's duration is
+    // the distance between its event and the previous one on the same lane (it includes the
+    // dependent-launch gap, as the single-lane series do).  ms[] = sum over the measured
+    // launches of both lanes, the first two iterations (phase settling) excluded.
+    std::vector<hipEvent_t> ev(6);
     for (auto &e : ev) SC_HIP(hipEventCreate(&e));
     int rc = 0;
-    SC_HIP(hipEventRecord(ev[0], s));
-    for (int it = 0; it < iters && !rc; it++) rc = launch_check(h, method, alpha_for(alpha, it + 1), g, h->d_synd, h->d_done, 0, s);
-    SC_HIP(hipEventRecord(ev[1], s));
-    SC_HIP(hipEventRecord(ev[2], s));
-    for (int it = 0; it < iters && !rc; it++) rc = launch_var(h, g, nullptr, h->d_hard, h->d_done, 0, 0, s);
-    SC_HIP(hipEventRecord(ev[3], s));
-    if (!rc) {
-        SC_HIP(hipStreamSynchronize(s));
-        SC_HIP(hipEventElapsedTime(&ms[0], ev[0], ev[1]));
-        SC_HIP(hipEventElapsedTime(&ms[1], ev[2], ev[3]));
-        launches[0] = iters;
-        launches[1] = iters;
-        launches[2] = g * TW;  // codewords swept per launch
+    if (nl < 2) {
+        SC_HIP(hipEventRecord(ev[0], s));
+        for (int it = 0; it < iters && !rc; it++) rc = launch_check(h, method, alpha_for(alpha, it + 1), g, h->d_synd, h->d_done, 0, s);
+        SC_HIP(hipEventRecord(ev[1], s));
+        SC_HIP(hipEventRecord(ev[2], s));
+        for (int it = 0; it < iters && !rc; it++) rc = launch_var(h, g, nullptr, h->d_hard, h->d_done, 0, 0, s);
+        SC_HIP(hipEventRecord(ev[3], s));
+        if (!rc) SC_HIP(hipStreamSynchronize(s));
+        if (!rc) {
+            SC_HIP(hipEventElapsedTime(&ms[0], ev[0], ev[1]));
+            SC_HIP(hipEventElapsedTime(&ms[1], ev[2], ev[3]));
+            launches[0] = launches[1] = iters;
+            launches[2] = launches[4] = g * TW;  // codewords swept per launch
+            launches[3] = 1;
+            launches[5] = 0;
+        }
+    } else {
+        if (!h->aux_stream[1]) {
+            int dev = 0;
+            SC_TRY(stream_acquire(&h->aux_stream[1], &dev));
+            SC_HIP(hipEventCreateWithFlags(&h->ev_join[1], hipEventDisableTiming));
+            SC_HIP(hipEventCreateWithFlags(&h->ev_phase[1], hipEventDisableTiming));
+        }
+        hipStream_t lane[2] = {s, h->aux_stream[1]};
+        const int gs[2] = {g - g / 2, g / 2}, t0[2] = {0, g - g / 2};  // as iterate_fixed_split deals the tiles
+        const int total = iters + 2;
+        std::vector<hipEvent_t> mark((size_t)2 * (2 * total + 1));  // per lane: start, then one per launch
+        for (auto &e : mark) SC_HIP(hipEventCreate(&e));
+        auto M = [&](int k, int i) -> hipEvent_t & { return mark[(size_t)k * (2 * total + 1) + i]; };
+        SC_HIP(hipEventRecord(ev[4], s));
+        SC_HIP(hipStreamWaitEvent(lane[1], ev[4], 0));
+        for (int it = 0; it < total && !rc; it++) {
+            for (int k = 0; k < 2 && !rc; k++) {
+                if (it == 0) SC_HIP(hipEventRecord(M(k, 0), lane[k]));
+                rc = launch_check(h, method, alpha_for(alpha, it + 1), gs[k], h->d_synd + (size_t)t0[k] * h->m, h->d_done + t0[k],
+                                  0, lane[k], false, t0[k]);
+                SC_HIP(hipEventRecord(M(k, 2 * it + 1), lane[k]));
+                if (it == 0 && k == 0) {
+                    SC_HIP(hipEventRecord(h->ev_phase[1], lane[0]));
+                    SC_HIP(hipStreamWaitEvent(lane[1], h->ev_phase[1], 0));
+                }
+            }
+            for (int k = 0; k < 2 && !rc; k++) {
+                rc = launch_var(h, gs[k], nullptr, h->d_hard + (size_t)t0[k] * h->n, h->d_done + t0[k], 0, 0, lane[k], t0[k]);
+                SC_HIP(hipEventRecord(M(k, 2 * it + 2), lane[k]));
+            }
+        }
+        SC_HIP(hipEventRecord(ev[5], lane[1]));
+        SC_HIP(hipStreamWaitEvent(s, ev[5], 0));
+        if (!rc) SC_HIP(hipStreamSynchronize(s));
+        if (!rc) {
+            double tc = 0.0, tv = 0.0;
+            int nc = 0, nv = 0;
+            for (int k = 0; k < 2; k++)
+                for (int it = 2; it < total; it++) {
+                    float d = 0.0f;
+                    SC_HIP(hipEventElapsedTime(&d, M(k, 2 * it), M(k, 2 * it + 1)));
+                    tc += d;
+                    nc++;
+                    SC_HIP(hipEventElapsedTime(&d, M(k, 2 * it + 1), M(k, 2 * it + 2)));
+                    tv += d;
+                    nv++;
+                }
+            ms[0] = (float)tc;
+            ms[1] = (float)tv;
+            launches[0] = nc;
+            launches[1] = nv;
+            launches[2] = gs[0] * TW;
+            launches[4] = gs[0] * TW;  // (odd groups: the second lane's launches are one tile smaller)
+            launches[3] = 2;
+            launches[5] = 0;
+        }
+        for (auto &e : mark) (void)hipEventDestroy(e);
     }
     for (auto &e : ev) (void)hipEventDestroy(e);
     return rc;
@@ -2484,6 +2635,11 @@ void scaldpc_bp_destroy(scaldpc_bp *h)
     CacheBypass guard(h->async_used);
     cached_free(h->h_remaining);
     if (h->own_stream) stream_release(h->own_stream, h->device);
+    for (int k = 0; k < 4; k++) {
+        if (h->aux_stream[k]) stream_release(h->aux_stream[k], h->device);
+        if (h->ev_join[k]) (void)hipEventDestroy(h->ev_join[k]);
+        if (h->ev_phase[k]) (void)hipEventDestroy(h->ev_phase[k]);
+    }
     delete h;
 }
 
