@@ -1289,7 +1289,7 @@ struct scaldpc_bp {
     int identity_from = -1;  // n - m if the last m columns of H are I_m (H = [Hin | I]), else -1
     hipStream_t own_stream = nullptr;
     int device = 0;  // the device the handle (and its stream) was created on
-    hipStream_t aux_stream[4] = {};  // further lanes of the fixed-iteration schedule (iterate_fixed_split)
+    hipStream_t aux_stream[4] = {};  // further lanes of a tile group (iterate_tiles)
     hipEvent_t ev_join[4] = {}, ev_phase[4] = {};
     // Set by the first SCALDPC_F_ASYNC call and never cleared: work may be in flight when a later call
     // (or destroy) releases a buffer, so this handle's blocks go back through hipFree (which
@@ -1639,11 +1639,11 @@ int iterate_el_early(scaldpc_bp *h, int nb, int max_iter, int method, float alph
     return 0;
 }
 
-// Fixed-iteration schedule of one tile group on SEVERAL streams ("lanes"): the group's tiles are
-// split into lanes whose launch sequences (independent: a pass depends only on the previous
-// pass over the same tiles) run one kernel out of phase, so that while one lane drains the tail
-// of its kernel another lane's kernel fills the machine.  Same kernels, same cache footprint,
-// same results.
+// All iterations of one tile group on the 64-codeword-tile kernels, on SEVERAL streams
+// ("lanes"): the group's tiles are dealt to lanes whose launch sequences (independent: a pass
+// depends only on the previous pass over the same tiles) run one kernel out of phase, so that
+// while one lane drains the tail of its kernel another lane's kernel fills the machine.  Same
+// kernels, same cache footprint, same results.  Early-exit runs join the lanes at every poll.
 constexpr int MAX_LANES = 4;
 // measured on the HQC-128 bench (4-tile groups, ms per 4096-codeword step): 1 lane 104.0,
 // 2 lanes 98.5, 3 lanes 101.3, 4 lanes 106.8 -- two kernels in flight fill each other's tails,
@@ -1655,10 +1655,8 @@ int fixed_lanes(const scaldpc_bp *h, int g)
     if (h->E == 0) return 1;
     return std::max(1, std::min(std::min(nl, g), MAX_LANES));
 }
-int iterate_fixed_split(scaldpc_bp *h, const TileState &st, int g0, int g, int max_iter, int method, float alpha,
-                        hipStream_t s, int nl)
+int ensure_lanes(scaldpc_bp *h, int nl)
 {
-    nl = std::min(std::min(nl, g), MAX_LANES);
     for (int k = 1; k < nl; k++)
         if (!h->aux_stream[k]) {
             int dev = 0;
@@ -1666,6 +1664,16 @@ int iterate_fixed_split(scaldpc_bp *h, const TileState &st, int g0, int g, int m
             SC_HIP(hipEventCreateWithFlags(&h->ev_join[k], hipEventDisableTiming));
             SC_HIP(hipEventCreateWithFlags(&h->ev_phase[k], hipEventDisableTiming));
         }
+    if (nl > 1 && !h->ev_join[0]) SC_HIP(hipEventCreateWithFlags(&h->ev_join[0], hipEventDisableTiming));  // [0]: the fork event
+    return 0;
+}
+int iterate_tiles(scaldpc_bp *h, const TileState &st, int g0, int g, int max_iter, int method, float alpha, bool early,
+                  int defer_after, hipStream_t s, bool *deferred, int real_codewords, int *poll_hint)
+{
+    const int poll_every = 4;
+    const int skip = early ? 1 : 0;
+    const int nl = fixed_lanes(h, g);
+    SC_TRY(ensure_lanes(h, nl));
     hipStream_t lane[MAX_LANES];
     int gs[MAX_LANES], t0[MAX_LANES];
     for (int k = 0, t = 0; k < nl; k++) {
@@ -1676,43 +1684,74 @@ int iterate_fixed_split(scaldpc_bp *h, const TileState &st, int g0, int g, int m
     }
     const int pw = parity_waves(h);
     const bool fused = fused_init(h, method);
-    if (!fused) {
+    if (h->E && !fused) {
         hipLaunchKernelGGL(k_init_msg, dim3((unsigned)((h->E + 3) / 4), g), dim3(256), 0, s, h->d_col_idx, h->d_prior,
                            h->d_msg, h->E);
         LAUNCH_CHECK();
     }
+    if (early) SC_HIP(hipMemsetAsync(h->d_remaining, 0, sizeof(int) * ((size_t)max_iter + 2), s));
+    if (nl > 1) {  // fork: the other lanes start after everything enqueued on `s` so far
+        SC_HIP(hipEventRecord(h->ev_join[0], s));
+        for (int k = 1; k < nl; k++) SC_HIP(hipStreamWaitEvent(lane[k], h->ev_join[0], 0));
+    }
+    auto join = [&]() -> int {
+        for (int k = 1; k < nl; k++) {
+            SC_HIP(hipEventRecord(h->ev_join[k], lane[k]));
+            SC_HIP(hipStreamWaitEvent(s, h->ev_join[k], 0));
+        }
+        return 0;
+    };
+    bool set_phase = true;  // (re-)establish the one-kernel offset between neighbouring lanes
     for (int it = 1; it <= max_iter; it++) {
         const bool last = it == max_iter;
         for (int k = 0; k < nl; k++) {
             const int ta = g0 + t0[k];
-            SC_TRY(launch_check(h, method, alpha_for(alpha, it), gs[k], st.synd + (size_t)ta * h->m, st.done + ta, 0, lane[k],
+            SC_TRY(launch_check(h, method, alpha_for(alpha, it), gs[k], st.synd + (size_t)ta * h->m, st.done + ta, skip, lane[k],
                                 fused && it == 1, t0[k]));
-            if (it == 1 && k + 1 < nl) {  // the next lane starts one kernel late (and after everything before the fork)
+            if (set_phase && k + 1 < nl) {
                 SC_HIP(hipEventRecord(h->ev_phase[k + 1], lane[k]));
                 SC_HIP(hipStreamWaitEvent(lane[k + 1], h->ev_phase[k + 1], 0));
             }
         }
+        set_phase = false;
         for (int k = 0; k < nl; k++) {
             const int ta = g0 + t0[k];
             SC_TRY(launch_var(h, gs[k], st.post ? st.post + (size_t)ta * h->n * TW : nullptr, st.hard + (size_t)ta * h->n,
-                              st.done + ta, 0, last ? 1 : 0, lane[k], t0[k]));
-            if (last) {
+                              st.done + ta, skip, (early || last) ? 1 : 0, lane[k], t0[k]));
+            if (early || last) {
                 hipLaunchKernelGGL(k_parity<true>, dim3((h->m + 4 * ROWS_PER_WAVE - 1) / (4 * ROWS_PER_WAVE), gs[k]), dim3(256),
                                    0, lane[k], h->d_row_ptr, h->d_col_idx, st.hard + (size_t)ta * h->n, h->m, h->n,
                                    const_cast<u64 *>(st.synd + (size_t)ta * h->m), st.unsat + (size_t)ta * pw,
                                    (const u64 *)(st.done + ta));
                 LAUNCH_CHECK();
-                hipLaunchKernelGGL(k_finalize, dim3(gs[k]), dim3(64), 0, lane[k], it, 0, st.done + ta, st.conv + ta,
+                hipLaunchKernelGGL(k_finalize, dim3(gs[k]), dim3(64), 0, lane[k], it, early ? 1 : 0, st.done + ta, st.conv + ta,
                                    st.unsat + (size_t)ta * pw, pw, st.iters + (size_t)ta * TW, h->d_remaining + it);
                 LAUNCH_CHECK();
             }
         }
+        // a poll drains the queue (the GPU idles while the host turns around): skip the poll
+        // points at which the call's earlier groups saw no codeword finish yet
+        const bool poll = (it % poll_every == 0 || it == 1 || it == defer_after) && (!poll_hint || it >= *poll_hint);
+        if (early && !last && poll) {
+            SC_TRY(join());
+            SC_HIP(hipMemcpyAsync(h->h_remaining + it, h->d_remaining + it, sizeof(int), hipMemcpyDeviceToHost, s));
+            SC_HIP(hipStreamSynchronize(s));
+            set_phase = true;
+            const int rem = h->h_remaining[it];
+            if (rem == 0) return 0;
+            if (poll_hint && rem >= real_codewords) *poll_hint = std::max(*poll_hint, it + 1);
+            // from `defer_after` on, any poll point may hand the stragglers over, provided the
+            // restart (it iterations redone) is cheap next to what is still ahead
+            // ... and the stragglers really get cheaper: fewer tiles, or few enough for the
+            // row-parallel kernels
+            const bool shrinks = (rem + TW - 1) / TW < g || rem <= el_limit(h, method);
+            if (defer_after > 0 && it >= defer_after && 2 * it < max_iter && 2 * rem <= real_codewords && shrinks) {
+                *deferred = true;
+                return 0;
+            }
+        }
     }
-    for (int k = 1; k < nl; k++) {
-        SC_HIP(hipEventRecord(h->ev_join[k], lane[k]));
-        SC_HIP(hipStreamWaitEvent(s, h->ev_join[k], 0));
-    }
-    return 0;
+    return join();
 }
 
 // el > 0: the group is ONE tile holding `el` codewords, decoded by the row-parallel kernels.
@@ -1720,64 +1759,42 @@ int iterate_group(scaldpc_bp *h, const TileState &st, int g0, int g, int max_ite
                   int defer_after, hipStream_t s, bool *deferred, int el = 0, int real_codewords = 0,
                   int *poll_hint = nullptr)
 {
-    const int poll_every = 4;
+    *deferred = false;
+    if (!el)
+        return iterate_tiles(h, st, g0, g, max_iter, method, alpha, early, defer_after, s, deferred, real_codewords, poll_hint);
     const int skip = early ? 1 : 0;
     const u64 *synd_g = st.synd + (size_t)g0 * h->m;
     u64 *hard_g = st.hard + (size_t)g0 * h->n;
     u64 *done_g = st.done + g0, *conv_g = st.conv + g0, *unsat_g = st.unsat + (size_t)g0 * parity_waves(h);
     int *iters_g = st.iters + (size_t)g0 * TW;
     float *post_g = st.post ? st.post + (size_t)g0 * h->n * TW : nullptr;
-    *deferred = false;
-    if (!el && !early && fixed_lanes(h, g) >= 2)
-        return iterate_fixed_split(h, st, g0, g, max_iter, method, alpha, s, fixed_lanes(h, g));
-    if (el && early && !(getenv("SCALDPC_EL_FUSE") && !strcmp(getenv("SCALDPC_EL_FUSE"), "0")))
+    if (early && !(getenv("SCALDPC_EL_FUSE") && !strcmp(getenv("SCALDPC_EL_FUSE"), "0")))
         return iterate_el_early(h, el, max_iter, method, alpha, synd_g, hard_g, done_g, conv_g, unsat_g, iters_g, post_g, s);
+    // row-parallel kernels, fixed iterations (or the four-launch early-exit form, SCALDPC_EL_FUSE=0)
     const bool fused = fused_init(h, method);
     if (h->E && !fused) {
-        if (el)
-            hipLaunchKernelGGL(k_el_init, dim3((unsigned)((h->E + 255) / 256), el), dim3(256), 0, s, h->d_col_idx,
-                               h->d_prior, h->d_emsg, h->E);
-        else
-            hipLaunchKernelGGL(k_init_msg, dim3((unsigned)((h->E + 3) / 4), g), dim3(256), 0, s, h->d_col_idx,
-                               h->d_prior, h->d_msg, h->E);
+        hipLaunchKernelGGL(k_el_init, dim3((unsigned)((h->E + 255) / 256), el), dim3(256), 0, s, h->d_col_idx, h->d_prior,
+                           h->d_emsg, h->E);
         LAUNCH_CHECK();
     }
     if (early) SC_HIP(hipMemsetAsync(h->d_remaining, 0, sizeof(int) * ((size_t)max_iter + 2), s));
     for (int it = 1; it <= max_iter; it++) {
         const bool last = it == max_iter;
-        if (el) {
-            SC_TRY(launch_el_check(h, method, alpha_for(alpha, it), el, synd_g, done_g, skip, s, fused && it == 1));
-            SC_TRY(launch_el_var(h, el, post_g, hard_g, done_g, skip, (early || last) ? 1 : 0, s));
-        } else {
-            SC_TRY(launch_check(h, method, alpha_for(alpha, it), g, synd_g, done_g, skip, s, fused && it == 1));
-            SC_TRY(launch_var(h, g, post_g, hard_g, done_g, skip, (early || last) ? 1 : 0, s));
-        }
+        SC_TRY(launch_el_check(h, method, alpha_for(alpha, it), el, synd_g, done_g, skip, s, fused && it == 1));
+        SC_TRY(launch_el_var(h, el, post_g, hard_g, done_g, skip, (early || last) ? 1 : 0, s));
         if (early || last) {
-            hipLaunchKernelGGL(k_parity<true>, dim3((h->m + 4 * ROWS_PER_WAVE - 1) / (4 * ROWS_PER_WAVE), g), dim3(256), 0, s, h->d_row_ptr, h->d_col_idx,
-                               hard_g, h->m, h->n, const_cast<u64 *>(synd_g), unsat_g, (const u64 *)done_g);
+            hipLaunchKernelGGL(k_parity<true>, dim3((h->m + 4 * ROWS_PER_WAVE - 1) / (4 * ROWS_PER_WAVE), 1), dim3(256), 0, s,
+                               h->d_row_ptr, h->d_col_idx, hard_g, h->m, h->n, const_cast<u64 *>(synd_g), unsat_g,
+                               (const u64 *)done_g);
             LAUNCH_CHECK();
-            hipLaunchKernelGGL(k_finalize, dim3(g), dim3(64), 0, s, it, early ? 1 : 0, done_g, conv_g, unsat_g, parity_waves(h), iters_g,
-                               h->d_remaining + it);
+            hipLaunchKernelGGL(k_finalize, dim3(1), dim3(64), 0, s, it, early ? 1 : 0, done_g, conv_g, unsat_g, parity_waves(h),
+                               iters_g, h->d_remaining + it);
             LAUNCH_CHECK();
         }
-        // a poll drains the queue (the GPU idles while the host turns around): skip the poll
-        // points at which the call's earlier groups saw no codeword finish yet
-        const bool poll = (it % poll_every == 0 || it == 1 || it == defer_after) && (!poll_hint || it >= *poll_hint);
-        if (early && !last && poll) {
+        if (early && !last && (it % 4 == 0 || it == 1)) {
             SC_HIP(hipMemcpyAsync(h->h_remaining + it, h->d_remaining + it, sizeof(int), hipMemcpyDeviceToHost, s));
             SC_HIP(hipStreamSynchronize(s));
-            const int rem = h->h_remaining[it];
-            if (rem == 0) break;
-            if (poll_hint && rem >= real_codewords) *poll_hint = std::max(*poll_hint, it + 1);
-            // from `defer_after` on, any poll point may hand the stragglers over, provided the
-            // restart (it iterations redone) is cheap next to what is still ahead
-            // ... and the stragglers really get cheaper: fewer tiles, or few enough for the
-            // row-parallel kernels
-            const bool shrinks = (rem + TW - 1) / TW < g || (!el && rem <= el_limit(h, method));
-            if (defer_after > 0 && it >= defer_after && 2 * it < max_iter && 2 * rem <= real_codewords && shrinks) {
-                *deferred = true;
-                break;
-            }
+            if (h->h_remaining[it] == 0) break;
         }
     }
     return 0;
@@ -2556,14 +2573,9 @@ int scaldpc_bp_time_kernels(scaldpc_bp *h, int32_t iters, int32_t method, float 
             launches[5] = 0;
         }
     } else {
-        if (!h->aux_stream[1]) {
-            int dev = 0;
-            SC_TRY(stream_acquire(&h->aux_stream[1], &dev));
-            SC_HIP(hipEventCreateWithFlags(&h->ev_join[1], hipEventDisableTiming));
-            SC_HIP(hipEventCreateWithFlags(&h->ev_phase[1], hipEventDisableTiming));
-        }
+        SC_TRY(ensure_lanes(h, 2));
         hipStream_t lane[2] = {s, h->aux_stream[1]};
-        const int gs[2] = {g - g / 2, g / 2}, t0[2] = {0, g - g / 2};  // as iterate_fixed_split deals the tiles
+        const int gs[2] = {g - g / 2, g / 2}, t0[2] = {0, g - g / 2};  // as iterate_tiles deals the tiles
         const int total = iters + 2;
         std::vector<hipEvent_t> mark((size_t)2 * (2 * total + 1));  // per lane: start, then one per launch
         for (auto &e : mark) SC_HIP(hipEventCreate(&e));
