@@ -1,0 +1,1035 @@
+// Device code of the binary BP path (included by scaldpc_bp.hip, which holds the handle,
+// the scheduling and the C ABI).  Everything lives in an anonymous namespace of that one
+// translation unit; the split is for reading, not for linking.
+#pragma once
+
+namespace {
+
+constexpr int TW = 64;       // codewords per tile = one wavefront of lanes
+constexpr int MAXB = 8;      // degree buckets per node kind
+constexpr int ROW_CAP = 64;  // largest register-resident row degree (also the sign-mask width)
+
+__device__ __forceinline__ int rfl(int x) { return __builtin_amdgcn_readfirstlane(x); }
+
+// Degree buckets of one fused launch: blocks [blk[b], blk[b+1]) work on the nodes
+// list[off[b] .. off[b]+cnt[b]) with unroll bound maxd[b] (0 = any-degree fallback).
+struct Buckets {
+    int nb;
+    int maxd[MAXB];
+    int off[MAXB];
+    int cnt[MAXB];
+    int blk[MAXB + 1];
+};
+
+// ---------------------------------------------------------------------------
+// input / output reshaping
+// ---------------------------------------------------------------------------
+// uint8 [batch][len] (one row per codeword, as decode() receives them) -> planes [tile][x].
+// wave = (tile, 16 consecutive x): lane c walks one 16-byte stretch of codeword c.
+// grid (ceil(len/64), T), block 256.
+__global__ __launch_bounds__(256) void k_pack_bits(const uint8_t *__restrict__ in, int len, int batch,
+                                                   u64 *__restrict__ out)
+{
+    const int lane = threadIdx.x & 63;
+    const int x0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 16;
+    const int t = blockIdx.y;
+    if (x0 >= len) return;
+    const long b = (long)t * TW + lane;
+    const uint8_t *p = in + (size_t)(b < batch ? b : 0) * len + x0;
+    const int nx = min(16, len - x0);
+    for (int j = 0; j < nx; j++) {
+        const int bit = (b < batch) ? (p[j] & 1) : 0;
+        const u64 w = __ballot(bit);
+        if (lane == 0) out[(size_t)t * len + x0 + j] = w;
+    }
+}
+
+// hard decision planes (XOR received planes) -> uint8 [batch][n].
+// grid (ceil(n/256), T), block 256: a thread owns one variable of one tile.
+__global__ __launch_bounds__(256) void k_unpack_bits(const u64 *__restrict__ hard, const u64 *__restrict__ recv,
+                                                     int n, int batch, uint8_t *__restrict__ out)
+{
+    const int v = blockIdx.x * 256 + threadIdx.x;
+    const int t = blockIdx.y;
+    if (v >= n) return;
+    u64 w = hard[(size_t)t * n + v];
+    if (recv) w ^= recv[(size_t)t * n + v];
+    const int nb = min(TW, batch - t * TW);
+    for (int c = 0; c < nb; c++) out[(size_t)(t * TW + c) * n + v] = (uint8_t)((w >> c) & 1);
+}
+
+// posterior [tile][var][64] -> float [batch][n] via an LDS transpose of 64 vars x 64 codewords.
+// grid (ceil(n/64), T), block 256.
+__global__ __launch_bounds__(256) void k_unpack_llr(const float *__restrict__ post, int n, int batch,
+                                                    float *__restrict__ out)
+{
+    __shared__ float tile[64][65];
+    const int t = blockIdx.y, v0 = blockIdx.x * 64;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    for (int j = w; j < 64; j += 4)
+        if (v0 + j < n) tile[j][lane] = post[((size_t)t * n + v0 + j) * TW + lane];
+    __syncthreads();
+    for (int c = w; c < 64; c += 4) {
+        const long b = (long)t * TW + c;
+        if (b < batch && v0 + lane < n) out[(size_t)b * n + v0 + lane] = tile[lane][c];
+    }
+}
+
+// conv planes + iteration counters -> int32 iters[batch], uint8 conv[batch].  grid T, block 64.
+__global__ __launch_bounds__(64) void k_unpack_state(const u64 *__restrict__ conv_bits, const int *__restrict__ iters,
+                                                     int batch, int *__restrict__ out_iters,
+                                                     uint8_t *__restrict__ out_conv)
+{
+    const int t = blockIdx.x, c = threadIdx.x;
+    const long b = (long)t * TW + c;
+    if (b >= batch) return;
+    if (out_iters) out_iters[b] = iters[b];
+    if (out_conv) out_conv[b] = (uint8_t)((conv_bits[t] >> c) & 1);
+}
+
+// ---------------------------------------------------------------------------
+// parity of bit planes along the rows of H.
+//   CHECK = false: synd[t][r] = XOR_v bits[t][v]          (received-vector mode: s = H v)
+//   CHECK = true : unsat[t][w] = OR_r (synd[t][r] ^ XOR_v bits) over wave w's rows (convergence test H e == s)
+// A wave takes ROWS_PER_WAVE consecutive rows of one tile, all in flight at once, its lanes
+// over a row's edges: the column indices of a row are one coalesced read, the 8-byte
+// plane words are gathered from L2 (n x 8 B per tile: 173 KB at HQC-128), the row parity is
+// an XOR butterfly over the wave.  Every wave stores its OR of mismatches in its own slot
+// (k_finalize folds the slots): no atomics, so the launch can be as wide as the row count
+// allows.  (History: a row per THREAD -- 51 dependent, uncoalesced index reads -- 27.7 us per
+// launch on the bench graph; 16 rows per wave one after the other with one atomicOr per wave,
+// 19 us, latency-bound at one wave per SIMD; this form: see DESIGN.md.)
+// grid (ceil(m / (4*ROWS_PER_WAVE)), T), block 256.
+// ---------------------------------------------------------------------------
+constexpr int ROWS_PER_WAVE = 4;
+
+template <bool CHECK>
+__global__ __launch_bounds__(256) void k_parity(const int *__restrict__ row_ptr, const int *__restrict__ col_idx,
+                                                const u64 *__restrict__ bits, int m, int n, u64 *__restrict__ synd,
+                                                u64 *__restrict__ unsat, const u64 *__restrict__ done)
+{
+    const int lane = threadIdx.x & 63;
+    const int t = blockIdx.y;
+    if (CHECK && done[t] == ~0ull) return;  // whole tile frozen
+    const int wv = blockIdx.x * 4 + (threadIdx.x >> 6);  // wave index inside the tile
+    const int r0 = wv * ROWS_PER_WAVE;
+    const u64 *bt = bits + (size_t)t * n;
+    u64 bad = 0;
+    // IL rows in flight: their index loads and plane gathers are independent, only the xor
+    // butterflies are not
+    constexpr int IL = 4;
+    const int rend = min(r0 + ROWS_PER_WAVE, m);
+    for (int rb = r0; rb < rend; rb += IL) {
+        u64 a[IL];
+        int ea[IL], eb[IL];
+#pragma unroll
+        for (int i = 0; i < IL; i++) {
+            const int r = min(rb + i, rend - 1);
+            ea[i] = rfl(row_ptr[r]) + lane;
+            eb[i] = rb + i < rend ? rfl(row_ptr[r + 1]) : 0;
+        }
+#pragma unroll
+        for (int i = 0; i < IL; i++) a[i] = ea[i] < eb[i] ? bt[col_idx[ea[i]]] : 0ull;  // first 64 edges of each row
+#pragma unroll
+        for (int i = 0; i < IL; i++)
+            for (int e = ea[i] + 64; e < eb[i]; e += 64) a[i] ^= bt[col_idx[e]];  // rows wider than a wave
+#pragma unroll
+        for (int i = 0; i < IL; i++) {
+            const int r = rb + i;
+            if (r >= rend) break;
+            u64 x = a[i];
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) x ^= __shfl_xor(x, off);
+            if (CHECK)
+                bad |= x ^ synd[(size_t)t * m + r];
+            else if (lane == 0)
+                synd[(size_t)t * m + r] = x;
+        }
+    }
+    if (CHECK && lane == 0) unsat[(size_t)t * (gridDim.x * 4) + wv] = bad;
+}
+
+// per-tile state reset.  grid T, block 64.
+__global__ __launch_bounds__(64) void k_init_state(int batch, int max_iter, u64 *__restrict__ done,
+                                                   u64 *__restrict__ conv, int *__restrict__ iters)
+{
+    const int t = blockIdx.x, c = threadIdx.x;
+    const long b = (long)t * TW + c;
+    iters[b] = max_iter;
+    const u64 pad = __ballot(b >= batch);  // padding codewords are born "done"
+    if (c == 0) {
+        done[t] = pad;
+        conv[t] = 0;
+    }
+}
+
+// Latch convergence after the parity test of iteration `it`.  grid G, block 64.
+//   latch = 1 (early exit): a codeword that satisfies H e == s for the first time is
+//           frozen: done bit set, iters = it, its outputs are no longer overwritten.
+//   latch = 0 (fixed iterations): only record whether the FINAL decision satisfies.
+// *remaining += number of codewords still running.
+// unsat: the `pw` per-wave words k_parity<true> just wrote for each tile (a tile it skipped
+// is all done: whatever its stale words say, nothing is latched).
+__global__ __launch_bounds__(64) void k_finalize(int it, int latch, u64 *__restrict__ done, u64 *__restrict__ conv,
+                                                 const u64 *__restrict__ unsat, int pw, int *__restrict__ iters,
+                                                 int *__restrict__ remaining)
+{
+    const int t = blockIdx.x, c = threadIdx.x;
+    const u64 dw = done[t];
+    u64 uw = 0;
+    if (dw != ~0ull) {
+        for (int i = c; i < pw; i += 64) uw |= unsat[(size_t)t * pw + i];
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) uw |= __shfl_xor(uw, off);
+    }
+    const u64 newly = ~dw & ~uw;
+    if (latch) {
+        if ((newly >> c) & 1) iters[(long)t * TW + c] = it;
+        if (c == 0) {
+            done[t] = dw | newly;
+            conv[t] |= newly;
+            const int rem = __popcll(~(dw | newly));
+            if (rem) atomicAdd(remaining, rem);
+        }
+    } else if (c == 0) {
+        conv[t] = newly;  // dw = padding here
+    }
+}
+
+// ---------------------------------------------------------------------------
+// K1  initial bit-to-check messages: msg[tile][e][:] = LLR prior of the edge's column.
+// grid (ceil(E/4), G), block 256 = 4 waves, wave = one 256 B edge row.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_init_msg(const int *__restrict__ col_idx, const float *__restrict__ prior,
+                                                  float *__restrict__ msg, long E)
+{
+    const int lane = threadIdx.x & 63;
+    const long e = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (e >= E) return;
+    msg[((size_t)blockIdx.y * E + e) * TW + lane] = prior[col_idx[e]];
+}
+
+// ---------------------------------------------------------------------------
+// K3  min-sum check-node update, in place.
+//   c2v_k = alpha * (-1)^(s + #{k' != k : v2c_k' <= 0}) * min_{k' != k} |v2c_k'|
+// The reference package obtains the exclusive minimum by a forward and a backward
+// running min; min is exact, so (min1, min2, first argmin) gives the identical
+// value with ONE pass over the inputs.  Signs of all inputs are kept in a 64-bit
+// mask per codeword (rows of degree <= 64); WIDE rows re-read the input instead
+// (reading edge k before overwriting edge k keeps that legal in place).
+// wave = (row, tile), lane = codeword.  grid (ceil(m/4), G), block 256 = 4 rows.
+// ---------------------------------------------------------------------------
+// FIRST: iteration 1 takes its inputs straight from the priors (v2c = prior of the edge's
+// column by definition), so the message array needs no initialisation pass and is not read.
+template <bool WIDE, bool FIRST>
+__global__ __launch_bounds__(256) void k_check_minsum(const int *__restrict__ row_ptr, float *msg,
+                                                      const u64 *__restrict__ synd, const u64 *__restrict__ done,
+                                                      int skip_done, int m, long E, float alpha,
+                                                      const int *__restrict__ col_idx, const float *__restrict__ prior)
+{
+    const int lane = threadIdx.x & 63;
+    int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= m) return;
+    r = rfl(r);
+    const int tl = blockIdx.y;
+    if (skip_done && done[tl] == ~0ull) return;
+    const int e0 = rfl(row_ptr[r]);
+    const int deg = rfl(row_ptr[r + 1]) - e0;
+    float *p = msg + ((size_t)tl * E + e0) * TW + lane;
+    unsigned par = (unsigned)(synd[(size_t)tl * m + r] >> lane) & 1u;
+    float m1 = FLT_MAX, m2 = FLT_MAX;
+    int ix = 0;
+    u64 neg = 0;
+#pragma unroll 8
+    for (int k = 0; k < deg; k++) {
+        const float x = FIRST ? prior[rfl(col_idx[e0 + k])] : p[(size_t)k * TW];
+        const float a = fabsf(x);
+        const unsigned n_ = x <= 0.0f;
+        par ^= n_;
+        if (!WIDE) neg |= (u64)n_ << k;
+        const bool lt = a < m1;
+        m2 = lt ? m1 : ((a < m2) ? a : m2);
+        ix = lt ? k : ix;
+        m1 = lt ? a : m1;
+    }
+    const float nalpha = -alpha;
+#pragma unroll 8
+    for (int k = 0; k < deg; k++) {
+        const unsigned b = WIDE ? (unsigned)((FIRST ? prior[rfl(col_idx[e0 + k])] : p[(size_t)k * TW]) <= 0.0f)
+                                : ((unsigned)(neg >> k) & 1u);
+        p[(size_t)k * TW] = ((k == ix) ? m2 : m1) * ((par ^ b) ? nalpha : alpha);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// K2  tanh-rule (sum-product) check-node update, LLR domain, fp32, COMPLEMENT form, in place.
+//   c2v_k = (-1)^(s + #{k' != k : x_k' < 0}) * 2 atanh( prod_{k' != k} tanh(|x_k'|/2) )
+// computed without the 1-x cancellation that saturates the textbook form at |L|~17
+// in fp32:   u_k = 1 - tanh(|x_k|/2) = 2 / (exp|x_k| + 1)
+//            U   = 1 - prod(1 - u)   via  U' = U + u (1 - U)     (forward and backward)
+//            |c2v_k| = log(2 / U_excl - 1),  U_excl = Upre + Usuf (1 - Upre)
+// Exact for |L| up to ~88 (then u underflows to 0 and L = +inf, which is also what
+// p = 0 priors feed in).  Same exclusive forward/backward sweep as the reference
+// package; the CPU oracle's method 3 is this sequence op for op.
+// Row values live in registers: straight-line code instantiated for the row's EXACT degree
+// (1..64, dispatched wave-uniformly), sign parity carried in the float sign bits.
+// ---------------------------------------------------------------------------
+// Device math for the tanh rule: the hardware transcendental units (v_exp_f32,
+// v_rcp_f32, v_log_f32; ~1 ulp each) instead of the ~100-instruction-per-edge
+// correctly rounded expf / logf / IEEE division, which made this kernel ALU-bound once
+// the messages were cache resident.  The complement form does not amplify these
+// errors (|dL| stays ~1e-6 relative, tests/helpers.compare states the tolerance).
+__device__ __forceinline__ float tanh_compl(float a)  // 1 - tanh(a/2) = 2 / (e^a + 1), a >= 0
+{
+    // raw v_exp_f32: e^a >= 1 here, so the denormal fix-ups of __expf are dead weight
+    return 2.0f * __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(a * 1.44269504088896340736f) + 1.0f);
+}
+__device__ __forceinline__ float llr_from_compl(float U)  // 2 atanh(1 - U) = log(2/U - 1), U in [0, 1]
+{
+    // 2/U - 1 >= 1: raw v_log_f32 needs no denormal handling either
+    return __builtin_amdgcn_logf(fmaf(2.0f, __builtin_amdgcn_rcpf(U), -1.0f)) * 0.69314718055994530942f;
+}
+// U' = U + u (1 - U), one rounding (the oracle's method 3 uses fmaf in the same places)
+__device__ __forceinline__ float compl_step(float U, float u) { return fmaf(u, 1.0f - U, U); }
+
+// FIRST: iteration 1 takes its inputs from the priors of the row's columns (cidx = the row's
+// slice of col_idx), so the message array needs no initialisation pass and is not read.
+template <int DEG, bool FIRST>
+__device__ __forceinline__ void check_tanh_row(float *p, unsigned sbit, const float *__restrict__ prior,
+                                               const int *__restrict__ cidx)
+{
+    // EXACT degree: straight-line code, no per-edge branches (a predicated `k < deg` unroll
+    // makes every edge its own basic block, and the compiler then waits for all memory
+    // traffic at each block entry).
+    // uu[k]: first the input x_k, then u_k >= 0 carrying the SIGN BIT of x_k (a -0.0 input
+    // counts as negative here; it forces every other output of the row to +-0, so only
+    // the sign of exact zeros can differ from the `x < 0` convention), finally the output.
+    float uu[DEG], pre[DEG];
+#pragma unroll
+    for (int k = 0; k < DEG; k++) uu[k] = FIRST ? prior[rfl(cidx[k])] : p[(size_t)k * TW];
+    unsigned acc = sbit << 31;  // running XOR of sign bits, syndrome folded in
+    float U = 0.0f;
+#pragma unroll
+    for (int k = 0; k < DEG; k++) {
+        const unsigned xb = __float_as_uint(uu[k]);
+        acc ^= xb;
+        const float u = tanh_compl(fabsf(uu[k]));
+        uu[k] = __uint_as_float(__float_as_uint(u) | (xb & 0x80000000u));
+        pre[k] = U;
+        U = compl_step(U, u);
+    }
+    U = 0.0f;
+#pragma unroll
+    for (int k = DEG - 1; k >= 0; k--) {
+        const float Ut = compl_step(pre[k], U);  // pre + U (1 - pre)
+        const float Lm = llr_from_compl(Ut);
+        const unsigned sg = (acc ^ __float_as_uint(uu[k])) & 0x80000000u;  // parity of the OTHER inputs
+        U = compl_step(U, fabsf(uu[k]));
+        p[(size_t)k * TW] = __uint_as_float(__float_as_uint(Lm) ^ sg);
+    }
+}
+
+// Any-degree fallback: the forward sweep parks Upre in a scratch array (the reference
+// package parks its prefix products in the message slot), the backward sweep re-reads
+// the inputs and recomputes u before overwriting them.
+__device__ __forceinline__ void check_tanh_row_generic(float *p, float *sc, int deg, unsigned sbit)
+{
+    float U = 0.0f;
+    unsigned par = sbit;
+    for (int k = 0; k < deg; k++) {
+        const float x = p[(size_t)k * TW];
+        sc[(size_t)k * TW] = U;
+        par ^= (unsigned)(x < 0.0f);
+        const float u = tanh_compl(fabsf(x));
+        U = compl_step(U, u);
+    }
+    U = 0.0f;
+    for (int k = deg - 1; k >= 0; k--) {
+        const float x = p[(size_t)k * TW];
+        const float pk = sc[(size_t)k * TW];
+        const float Ut = compl_step(pk, U);
+        const float Lm = llr_from_compl(Ut);
+        p[(size_t)k * TW] = ((par ^ (unsigned)(x < 0.0f)) & 1u) ? -Lm : Lm;
+        const float u = tanh_compl(fabsf(x));
+        U = compl_step(U, u);
+    }
+}
+
+// One fused launch over all rows (the bucket table only separates the register-resident
+// rows, degree <= 64, from the any-degree fallback; its lists are sorted by degree so that
+// neighbouring waves run the same instantiation).  wave = (row, tile).
+// CAP = largest degree compiled in (the register budget follows the widest instantiation,
+// so graphs with narrow rows get the high-occupancy build).
+// grid (bk.blk[nb], G), block 256 = 4 rows of one bucket.
+template <int CAP, bool FIRST>
+__global__ __launch_bounds__(256) void k_check_tanh(Buckets bk, const int *__restrict__ list,
+                                                    const int *__restrict__ row_ptr, float *msg, float *scratch,
+                                                    const u64 *__restrict__ synd, const u64 *__restrict__ done,
+                                                    int skip_done, int m, long E, const int *__restrict__ col_idx,
+                                                    const float *__restrict__ prior)
+{
+    const int lane = threadIdx.x & 63;
+    const int tl = blockIdx.y;
+    // one descriptor per WAVE of the launch: {row or -1 (padding), first edge, degree, 0 = any-degree
+    // fallback}: a single load instead of bucket table -> row list -> row_ptr
+    const int4 md = ((const int4 *)list)[(size_t)blockIdx.x * 4 + (threadIdx.x >> 6)];
+    if (skip_done && done[tl] == ~0ull) return;
+    const int r = rfl(md.x);
+    if (r < 0) return;
+    const int e0 = rfl(md.y);
+    const int deg = rfl(md.z);
+    const size_t base = ((size_t)tl * E + e0) * TW + lane;
+    float *p = msg + base;
+    const unsigned sbit = (unsigned)(synd[(size_t)tl * m + r] >> lane) & 1u;
+    // dispatch on the row's exact degree (wave-uniform); CAP bounds what is compiled in
+#define TR(D)                                                                              \
+    case D:                                                                                \
+        if constexpr (D <= CAP) check_tanh_row<D, FIRST>(p, sbit, prior, col_idx + e0);    \
+        break;
+#define TR8(D) TR(D) TR(D + 1) TR(D + 2) TR(D + 3) TR(D + 4) TR(D + 5) TR(D + 6) TR(D + 7)
+    if (rfl(md.w) == 0) {
+        check_tanh_row_generic(p, scratch + base, deg, sbit);
+    } else {
+        switch (deg) {
+            TR(1) TR(2) TR(3) TR(4) TR(5) TR(6) TR(7)
+            TR8(8) TR8(16) TR8(24) TR8(32) TR8(40) TR8(48) TR8(56)
+            TR(64)
+            default: break;
+        }
+    }
+#undef TR8
+#undef TR
+}
+
+// ---------------------------------------------------------------------------
+// LDS-resident decoder for small graphs (the reference's own FER commands: n = 13 ... 1500,
+// E <= 4500, main.py:189-276).  When a codeword's whole message state fits one CU's LDS
+// (2 E floats + n + m bytes), ONE launch decodes the batch: workgroup = codeword, the
+// messages never leave LDS, all iterations and the H e == s early exit run inside the
+// kernel (no per-iteration launches, no host polling, no HBM/cache traffic at all).
+// Threads take rows in the check phase and columns in the variable phase and sweep their
+// edges sequentially in the reference package's order, so every value is bit-identical
+// to the streaming kernels' (same operations, same order, same device math).
+//   LDS: msg[E] (in place v2c <-> c2v), scr[E] (prefix sums / prefix products),
+//        hard[n], synd[m], recv[n] (received-vector mode), flag.
+// grid = batch, block = 256.
+// ---------------------------------------------------------------------------
+// PLANES = false: byte I/O as decode() hands it over (in: [batch][m or n], out_bits [batch][n]).
+// PLANES = true : bit-plane I/O for the Monte-Carlo entry points (in = syndrome planes
+//                 u64 [tile][m]; out_bits = hard planes u64 [tile][n], zeroed by the caller;
+//                 out_conv = conv planes u64 [tile]; out_llr = posterior [tile][var][64]).
+template <int METHOD, bool PLANES>  // METHOD: SCALDPC_BP_PRODUCT_SUM / SCALDPC_BP_MIN_SUM
+__global__ __launch_bounds__(256) void k_bp_small(const int *__restrict__ row_ptr, const int *__restrict__ col_idx,
+                                                  const int *__restrict__ col_ptr, const int *__restrict__ csc_edge,
+                                                  const float *__restrict__ prior, int m, int n, int E,
+                                                  const void *__restrict__ in_, int kind, int max_iter, float alpha0,
+                                                  int early, void *__restrict__ out_bits_,
+                                                  float *__restrict__ out_llr, int *__restrict__ out_iters,
+                                                  void *__restrict__ out_conv_)
+{
+    const uint8_t *in = (const uint8_t *)in_;
+    uint8_t *out_bits = (uint8_t *)out_bits_;
+    uint8_t *out_conv = (uint8_t *)out_conv_;
+    const u64 *in_planes = (const u64 *)in_;
+    u64 *hard_planes = (u64 *)out_bits_;
+    u64 *conv_planes = (u64 *)out_conv_;
+    extern __shared__ float sm[];
+    float *msg = sm, *scr = sm + E;
+    uint8_t *hard = (uint8_t *)(scr + E);
+    uint8_t *synd = hard + n;
+    uint8_t *recv = synd + m;  // n bytes, received-vector mode only
+    __shared__ int flag;
+    const int b = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
+    const int pt = b >> 6, pc = b & 63;  // tile / bit of this codeword in plane I/O
+
+    if (PLANES) {
+        for (int r = tid; r < m; r += nt) synd[r] = (uint8_t)((in_planes[(size_t)pt * m + r] >> pc) & 1);
+    } else if (kind == SCALDPC_IN_SYNDROME) {
+        for (int r = tid; r < m; r += nt) synd[r] = in[(size_t)b * m + r] & 1;
+    } else {
+        for (int v = tid; v < n; v += nt) recv[v] = in[(size_t)b * n + v] & 1;
+        __syncthreads();
+        for (int r = tid; r < m; r += nt) {
+            uint8_t p = 0;
+            for (int e = row_ptr[r]; e < row_ptr[r + 1]; e++) p ^= recv[col_idx[e]];
+            synd[r] = p;
+        }
+    }
+    for (int e = tid; e < E; e += nt) msg[e] = prior[col_idx[e]];
+    for (int v = tid; v < n; v += nt) hard[v] = 0;
+    __syncthreads();
+
+    int it_done = max_iter, conv = 0;
+    for (int it = 1; it <= max_iter; it++) {
+        const bool last = it == max_iter;
+        // ---- check nodes ----
+        if (METHOD == SCALDPC_BP_MIN_SUM) {
+            const float alpha = alpha0 == 0.0f ? (float)(1.0 - exp2(-(double)it)) : alpha0;
+            const float nalpha = -alpha;
+            for (int r = tid; r < m; r += nt) {
+                const int e0 = row_ptr[r], e1 = row_ptr[r + 1];
+                float m1 = FLT_MAX, m2 = FLT_MAX;
+                int ix = e0;
+                unsigned par = synd[r];
+                for (int e = e0; e < e1; e++) {
+                    const float x = msg[e];
+                    const float a = fabsf(x);
+                    par ^= (unsigned)(x <= 0.0f);
+                    const bool lt = a < m1;
+                    m2 = lt ? m1 : ((a < m2) ? a : m2);
+                    ix = lt ? e : ix;
+                    m1 = lt ? a : m1;
+                }
+                for (int e = e0; e < e1; e++) {
+                    const unsigned nb = msg[e] <= 0.0f;
+                    msg[e] = ((e == ix) ? m2 : m1) * ((par ^ nb) ? nalpha : alpha);
+                }
+            }
+        } else {
+            for (int r = tid; r < m; r += nt) {
+                const int e0 = row_ptr[r], e1 = row_ptr[r + 1];
+                float U = 0.0f;
+                unsigned par = synd[r];
+                for (int e = e0; e < e1; e++) {
+                    const float x = msg[e];
+                    scr[e] = U;
+                    par ^= (unsigned)(x < 0.0f);
+                    const float u = tanh_compl(fabsf(x));
+                    U = compl_step(U, u);
+                }
+                U = 0.0f;
+                for (int e = e1 - 1; e >= e0; e--) {
+                    const float x = msg[e];
+                    const float pk = scr[e];
+                    const float Ut = compl_step(pk, U);
+                    const float Lm = llr_from_compl(Ut);
+                    msg[e] = ((par ^ (unsigned)(x < 0.0f)) & 1u) ? -Lm : Lm;
+                    const float u = tanh_compl(fabsf(x));
+                    U = compl_step(U, u);
+                }
+            }
+        }
+        __syncthreads();
+        // ---- variable nodes ----
+        const bool outs = early || last;
+        for (int v = tid; v < n; v += nt) {
+            const int c0 = col_ptr[v], c1 = col_ptr[v + 1];
+            float temp = prior[v];
+            for (int t = c0; t < c1; t++) {
+                const int e = csc_edge[t];
+                scr[e] = temp;
+                temp += msg[e];
+            }
+            float suf = 0.0f;
+            for (int t = c1 - 1; t >= c0; t--) {
+                const int e = csc_edge[t];
+                const float mk = msg[e];
+                msg[e] = scr[e] + suf;
+                suf += mk;
+            }
+            if (outs) {
+                hard[v] = temp <= 0.0f;
+                if (out_llr) out_llr[PLANES ? ((size_t)pt * n + v) * TW + pc : (size_t)b * n + v] = temp;
+            }
+        }
+        if (tid == 0) flag = 0;
+        __syncthreads();
+        // ---- H e == s ? ----
+        if (outs) {
+            for (int r = tid; r < m; r += nt) {
+                uint8_t p = synd[r];
+                for (int e = row_ptr[r]; e < row_ptr[r + 1]; e++) p ^= hard[col_idx[e]];
+                if (p) flag = 1;
+            }
+            __syncthreads();
+            conv = !flag;
+            if (conv && early) {
+                it_done = it;
+                break;
+            }
+        }
+    }
+    if (PLANES) {
+        for (int v = tid; v < n; v += nt)
+            if (hard[v]) atomicOr(hard_planes + (size_t)pt * n + v, 1ull << pc);
+        if (tid == 0) {
+            out_iters[b] = it_done;
+            if (conv) atomicOr(conv_planes + pt, 1ull << pc);
+        }
+        return;
+    }
+    for (int v = tid; v < n; v += nt)
+        out_bits[(size_t)b * n + v] = hard[v] ^ (kind == SCALDPC_IN_RECEIVED ? recv[v] : (uint8_t)0);
+    if (tid == 0) {
+        if (out_iters) out_iters[b] = it_done;
+        if (out_conv) out_conv[b] = (uint8_t)conv;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// K4  variable-node update + posterior + hard decision, in place.
+//   prefix : v2c_k = prior + sum_{k'<k} c2v_k'      (ascending row)
+//   total  : L = prior + sum_k c2v_k ; e = [L <= 0]
+//   suffix : v2c_k += sum_{k'>k} c2v_k'             (accumulated from the last edge)
+// Column values live in registers (unrolled to MAXD, predicated on the uniform degree: for this
+// gather kernel the lower register count of the bucketed form (70 VGPRs, 7 waves/SIMD) beats
+// exact-degree straight-line code (131 VGPRs): 68.6 vs 74.9 us).
+// Returns the posterior L.
+// ---------------------------------------------------------------------------
+template <int MAXD>
+__device__ __forceinline__ float var_col(float *mt, const int *__restrict__ ce, int d, float pr)
+{
+    float mm[MAXD], pp[MAXD];
+#pragma unroll
+    for (int k = 0; k < MAXD; k++)
+        if (k < d) mm[k] = mt[(size_t)rfl(ce[k]) * TW];
+    float temp = pr;
+#pragma unroll
+    for (int k = 0; k < MAXD; k++)
+        if (k < d) {
+            pp[k] = temp;
+            temp += mm[k];
+        }
+    float suf = 0.0f;
+#pragma unroll
+    for (int k = MAXD - 1; k >= 0; k--)
+        if (k < d) {
+            mt[(size_t)rfl(ce[k]) * TW] = pp[k] + suf;
+            suf += mm[k];
+        }
+    return temp;
+}
+
+// Any-degree fallback: prefix parked in the scratch array, second sweep re-reads c2v
+// just before overwriting it.
+__device__ __forceinline__ float var_col_generic(float *mt, float *st, const int *__restrict__ ce, int d, float pr)
+{
+    float temp = pr;
+    for (int k = 0; k < d; k++) {
+        const size_t o = (size_t)ce[k] * TW;
+        st[o] = temp;
+        temp += mt[o];
+    }
+    float suf = 0.0f;
+    for (int k = d - 1; k >= 0; k--) {
+        const size_t o = (size_t)ce[k] * TW;
+        const float mk = mt[o];
+        mt[o] = st[o] + suf;
+        suf += mk;
+    }
+    return temp;
+}
+
+// One fused launch over all column-degree buckets.  wave = (column, tile), lane = codeword.
+// grid (bk.blk[nb], G), block 256 = 4 columns of one bucket.
+// write_out: also emit hard-decision planes (merged under the done mask) and, if
+// `post` is non-null, the posterior of every not-yet-frozen codeword.
+// CAP = largest unroll bound compiled in (see k_check_tanh).
+template <int CAP>
+__global__ __launch_bounds__(256) void k_var(Buckets bk, const int *__restrict__ list,
+                                             const int *__restrict__ col_ptr, const int *__restrict__ csc_edge,
+                                             const float *__restrict__ prior, float *msg, float *scratch,
+                                             float *__restrict__ post, u64 *__restrict__ hard,
+                                             const u64 *__restrict__ done, int skip_done, int n, long E,
+                                             int write_out)
+{
+    const int lane = threadIdx.x & 63;
+    const int tl = blockIdx.y;
+    // one 16-byte descriptor per WAVE of the launch: {column or -1 (padding of a bucket's last
+    // block), start in the re-laid edge list, degree, unroll bound of the bucket}: the wave's
+    // whole prologue is this one load (walking the bucket table first cost a chain of
+    // dependent scalar loads); `csc_edge` here is the edge list laid out in launch order
+    const int4 md = ((const int4 *)list)[(size_t)blockIdx.x * 4 + (threadIdx.x >> 6)];
+    const u64 dn = done[tl];
+    if (skip_done && dn == ~0ull) return;
+    const int v = rfl(md.x);
+    if (v < 0) return;
+    const int cb = rfl(md.y);
+    const int d = rfl(md.z);
+    float *mt = msg + (size_t)tl * E * TW + lane;
+    const int *ce = csc_edge + cb;
+    const float pr = prior[v];
+    float L = pr;
+    switch (rfl(md.w)) {
+        case 1: L = var_col<1>(mt, ce, d, pr); break;
+        case 2: L = var_col<2>(mt, ce, d, pr); break;
+        case 4: L = var_col<4>(mt, ce, d, pr); break;
+        case 8: L = var_col<8>(mt, ce, d, pr); break;
+        case 16: L = var_col<16>(mt, ce, d, pr); break;
+        case 32:
+            if constexpr (CAP >= 32) L = var_col<32>(mt, ce, d, pr);
+            break;
+        case 64:
+            if constexpr (CAP >= 64) L = var_col<64>(mt, ce, d, pr);
+            break;
+        default: L = var_col_generic(mt, scratch + (size_t)tl * E * TW + lane, ce, d, pr);
+    }
+    if (write_out) {
+        const u64 hb = __ballot(L <= 0.0f);
+        const size_t hi = (size_t)tl * n + v;
+        if (lane == 0) hard[hi] = (hard[hi] & dn) | (hb & ~dn);
+        if (post && !((dn >> lane) & 1)) post[hi * TW + lane] = L;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Row-parallel ("edge-lane") kernels for a HANDFUL of codewords on a graph too large for
+// LDS: the single `decode()` of the attack loop (hqc.py:708 -- one codeword, n ~ 20 000,
+// up to 100 iterations) and the few stragglers the compact pass re-decodes.  A 64-codeword
+// tile would stream 64 lanes of messages to use one; here the layout is per codeword
+//     emsg : float [codeword][edge]          (CSR order: a row's messages are contiguous)
+// and a wave owns one (row, codeword): LANE = EDGE of the row.  The row's messages are
+// one coalesced load, reductions over the row are wave primitives (ballot / popcount for
+// the sign parity, xor-shuffle butterflies for the two minima), the tanh rule's exclusive
+// forward/backward products walk the row with v_readlane broadcasts IN THE REFERENCE'S
+// ORDER, so every value is bit-identical to the tile kernels'.  State (syndrome, hard
+// decisions, done / unsat masks, posterior) stays in the tile formats: the codewords are
+// bits 0..nb-1 of one tile, so k_parity / k_finalize and all I/O kernels are shared.
+// Rows of degree <= 64 only (the host falls back to the tile path otherwise).
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ float wave_min_f(float v)
+{
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v = fminf(v, __shfl_xor(v, off));
+    return v;
+}
+__device__ __forceinline__ float readlane_f(float v, int l)
+{
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));
+}
+
+// unused by default (both rules' first check pass reads the priors); kept for rows the fused form does not cover.  grid (ceil(E/256), nb).
+__global__ __launch_bounds__(256) void k_el_init(const int *__restrict__ col_idx, const float *__restrict__ prior,
+                                                 float *__restrict__ emsg, long E)
+{
+    const long e = (long)blockIdx.x * 256 + threadIdx.x;
+    if (e < E) emsg[(size_t)blockIdx.y * E + e] = prior[col_idx[e]];
+}
+
+// METHOD as in the C ABI; FIRST: inputs are the priors (iteration 1).
+// grid (ceil(m/4), nb), block 256 = 4 rows of codeword blockIdx.y.
+template <int METHOD, bool FIRST>
+__global__ __launch_bounds__(256) void k_el_check(const int *__restrict__ row_ptr, const int *__restrict__ col_idx,
+                                                  const float *__restrict__ prior, float *emsg,
+                                                  const u64 *__restrict__ synd, const u64 *__restrict__ done,
+                                                  int skip_done, int m, long E, float alpha,
+                                                  const u64 *__restrict__ hard, int *__restrict__ unsat_prev)
+{
+    const int lane = threadIdx.x & 63;
+    int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= m) return;
+    r = rfl(r);
+    const int c = blockIdx.y;
+    if (skip_done && ((done[0] >> c) & 1)) return;  // frozen codeword
+    const int e0 = rfl(row_ptr[r]);
+    const int deg = rfl(row_ptr[r + 1]) - e0;
+    const bool act = lane < deg;
+    const unsigned sbit = (unsigned)(synd[r] >> c) & 1u;
+    // Early-exit runs: the H e == s test of the PREVIOUS iteration's decisions rides on this
+    // pass (the wave has the row anyway), k_el_var latches the verdict: two launches per
+    // iteration instead of four.  A flag per codeword, set by any unsatisfied row.
+    if (unsat_prev) {
+        const unsigned hb = act ? (unsigned)(hard[col_idx[e0 + lane]] >> c) & 1u : 0u;
+        if ((((unsigned)__popcll(__ballot(hb != 0u)) & 1u) ^ sbit) && lane == 0) unsat_prev[c] = 1;
+    }
+    if (deg == 0) return;
+    float *p = emsg + (size_t)c * E + e0 + lane;
+    float x = 0.0f;
+    if (act) x = FIRST ? prior[col_idx[e0 + lane]] : *p;
+    if (METHOD == SCALDPC_BP_MIN_SUM) {
+        // the sequential form starts its running minima at FLT_MAX: |x| = inf never wins
+        const float a = act ? fminf(fabsf(x), FLT_MAX) : FLT_MAX;
+        const bool ng = act && x <= 0.0f;
+        const unsigned par = sbit ^ ((unsigned)__popcll(__ballot(ng)) & 1u);
+        const float m1 = wave_min_f(a);
+        const int ix = __ffsll((long long)__ballot(act && a == m1)) - 1;  // first arg-min
+        const float m2 = wave_min_f(lane == ix ? FLT_MAX : a);
+        if (act) *p = ((lane == ix) ? m2 : m1) * ((par ^ (unsigned)ng) ? -alpha : alpha);
+    } else {
+        const unsigned xb = act ? __float_as_uint(x) : 0u;
+        const float u = act ? tanh_compl(fabsf(x)) : 0.0f;
+        const unsigned par = sbit ^ ((unsigned)__popcll(__ballot((xb >> 31) != 0u)) & 1u);
+        float pre = 0.0f, suf = 0.0f;  // exclusive forward / backward complements of this lane's edge
+#pragma unroll 4
+        for (int t = 0; t < deg; t++) {
+            const float nv = compl_step(pre, readlane_f(u, t));
+            pre = (t < lane) ? nv : pre;
+        }
+#pragma unroll 4
+        for (int t = deg - 1; t >= 0; t--) {
+            const float nv = compl_step(suf, readlane_f(u, t));
+            suf = (t > lane) ? nv : suf;
+        }
+        const float Lm = llr_from_compl(compl_step(pre, suf));
+        const unsigned sg = ((par << 31) ^ xb) & 0x80000000u;  // parity of the OTHER inputs
+        if (act) *p = __uint_as_float(__float_as_uint(Lm) ^ sg);
+    }
+}
+
+// Variable nodes, lane = EDGE OF A COLUMN.  The host packs whole columns (in degree order) into
+// waves of 64 lane slots (a column of degree d takes max(d, 1) neighbouring slots); a slot is
+// {edge id or -1, first lane of the column's segment | position << 6 | degree << 13 | valid << 20},
+// a wave additionally knows {its largest degree, the index of its first column in `cols`}.
+// All of a wave's messages arrive with ONE gather (a thread walking its column alone pays a
+// dependent cross-XCD load per edge: 25 us per pass), then the exclusive prefix / suffix sums
+// run over the segment with per-lane shuffles in the reference's sequential order:
+//   pre_k = ((prior + m_0) + ... + m_{k-1}),  suf_k = ((0 + m_{d-1}) + ... + m_{k+1}),  out_k = pre_k + suf_k
+// exactly the values var_col produces.  The segment's first lane owns the column (prior in,
+// posterior and hard decision out); the codewords of one tile word are set / cleared with
+// atomics (each launch row owns one bit).
+// grid (waves padded to a multiple of 8 over 4, nb), block 256 = 4 packed waves.
+__global__ __launch_bounds__(256) void k_el_var(const int2 *__restrict__ slots, const int2 *__restrict__ wave_info,
+                                                const int *__restrict__ cols, int nwaves,
+                                                const float *__restrict__ prior, float *emsg,
+                                                float *__restrict__ post, u64 *__restrict__ hard,
+                                                u64 *done, int skip_done, long E, int write_out,
+                                                const int *__restrict__ unsat_prev, int it_prev, u64 *conv,
+                                                int *__restrict__ iters, int *__restrict__ remaining_prev)
+{
+    const int lane = threadIdx.x & 63;
+    int w = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (w >= nwaves) return;
+    w = rfl(w);
+    const int c = blockIdx.y;
+    const bool frozen = (done[0] >> c) & 1;
+    if (skip_done && frozen) return;  // frozen codeword
+    if (unsat_prev) {
+        // verdict of k_el_check's fused test: no unsatisfied row => the codeword converged at
+        // iteration it_prev; its outputs (written by the previous launch of this kernel) stay,
+        // the first wave of its launch row records the fact.  Every wave of the row takes the
+        // same branch: the flags are read-only here and `done` only gains this very bit.
+        const bool newly = !frozen && unsat_prev[c] == 0;
+        if (newly) {
+            if (w == 0 && lane == 0) {
+                atomicOr(done, 1ull << c);
+                atomicOr(conv, 1ull << c);
+                iters[c] = it_prev;
+            }
+            return;
+        }
+        if (w == 0 && lane == 0 && !frozen) atomicAdd(remaining_prev, 1);
+    }
+    const int2 sl = slots[(size_t)w * 64 + lane];
+    const int e = sl.x, start = sl.y & 63, pos = (sl.y >> 6) & 127, deg = (sl.y >> 13) & 127;
+    const bool head = ((sl.y >> 20) & 1) && pos == 0;  // first lane of a column's segment
+    const int2 wi = wave_info[w];
+    const int dmax = rfl(wi.x);
+    float *mt = emsg + (size_t)c * E;
+    const float mk = e >= 0 ? mt[e] : 0.0f;
+    // the column id of a segment = (number of heads before it)-th column of this wave
+    const u64 heads = __ballot(head);
+    int v = 0;
+    float pr = 0.0f;
+    if (head) {
+        v = cols[rfl(wi.y) + __popcll(heads & ((1ull << lane) - 1))];
+        pr = prior[v];
+    }
+    pr = __shfl(pr, start);
+    float pre = pr, tot = pr, suf = 0.0f;
+    for (int t = 0; t < dmax; t++) {
+        const float val = __shfl(mk, (start + t) & 63);
+        pre = (t < pos) ? pre + val : pre;
+        tot = (t < deg) ? tot + val : tot;
+    }
+    for (int t = dmax - 1; t >= 0; t--) {
+        const float val = __shfl(mk, (start + t) & 63);
+        suf = (t > pos && t < deg) ? suf + val : suf;
+    }
+    if (e >= 0) mt[e] = pre + suf;
+    if (write_out && head) {
+        if (tot <= 0.0f)
+            atomicOr(hard + v, 1ull << c);
+        else
+            atomicAnd(hard + v, ~(1ull << c));
+        if (post) post[(size_t)v * TW + c] = tot;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// K6  Monte-Carlo helpers: per-trial noise sampling, syndrome and success compare on the
+// device (the reference does these per position in Python: simulate/decode.py:36-40,
+// 166-168, 173-175; simulate/hqc.py:684-705, 742-749).
+// Random numbers: Philox4x32-10 (Salmon et al., SC'11), counter-based, keyed by the seed;
+// counter = (block, stream, trial_lo, trial_hi) with the GLOBAL trial index, so a trial's
+// inputs do not depend on batch size, tile position or the number of GPUs.
+//   stream 0 word x : Bernoulli(p_x) for position x      (flip iff word < floor(p_x * 2^32))
+//   stream 1 word j : j-th candidate position of the HQC secret, pos = mulhi(word, N),
+//                     accepted if not chosen before, until omega are accepted
+// ---------------------------------------------------------------------------
+struct U4 { unsigned x, y, z, w; };
+
+__device__ __forceinline__ U4 philox4x32_10(U4 c, unsigned k0, unsigned k1)
+{
+#pragma unroll
+    for (int r = 0; r < 10; r++) {
+        const unsigned hi0 = __umulhi(0xD2511F53u, c.x), lo0 = 0xD2511F53u * c.x;
+        const unsigned hi1 = __umulhi(0xCD9E8D57u, c.z), lo1 = 0xCD9E8D57u * c.z;
+        c = U4{hi1 ^ c.y ^ k0, lo1, hi0 ^ c.w ^ k1, lo0};
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    return c;
+}
+
+// planes[t][x] (bit c) = [stream-`stream` word x of trial first + 64 t + c  <  thr_x]; XOR_INTO flips
+// an existing plane instead.  wave = (tile, 16 consecutive x).  grid (ceil(len/64), T), block 256.
+template <bool XOR_INTO>
+__global__ __launch_bounds__(256) void k_mc_bernoulli(u64 *__restrict__ planes, int len, int batch, long first,
+                                                      unsigned stream, unsigned k0, unsigned k1,
+                                                      const u64 *__restrict__ thr, u64 thr0)
+{
+    const int lane = threadIdx.x & 63;
+    const int x0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 16;
+    const int t = blockIdx.y;
+    if (x0 >= len) return;
+    const long b = (long)t * TW + lane;
+    const u64 trial = (u64)(first + b);
+    for (int q = 0; q < 4; q++) {
+        const int xb = x0 + 4 * q;
+        if (xb >= len) break;
+        const U4 r = philox4x32_10(U4{(unsigned)(xb >> 2), stream, (unsigned)trial, (unsigned)(trial >> 32)}, k0, k1);
+        const unsigned w[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int x = xb + j;
+            if (x < len) {
+                const u64 th = thr ? thr[x] : thr0;
+                const u64 m = __ballot(b < batch && (u64)w[j] < th);
+                if (lane == 0) {
+                    if (XOR_INTO)
+                        planes[(size_t)t * len + x] ^= m;
+                    else
+                        planes[(size_t)t * len + x] = m;
+                }
+            }
+        }
+    }
+}
+
+// HQC secret: omega distinct positions per trial, set as bits of planes[t][pos] (pos < N; the
+// plane rows have stride n).  One wave per tile, lane = trial; chosen positions kept in LDS.
+// grid T, block 64, dynamic LDS omega*64*4 B.
+__global__ __launch_bounds__(64) void k_mc_hqc_secret(u64 *__restrict__ planes, int n, int N, int omega, int batch,
+                                                      long first, unsigned k0, unsigned k1, int *__restrict__ out_y)
+{
+    extern __shared__ int chosen[];  // [omega][64]
+    const int lane = threadIdx.x, t = blockIdx.x;
+    const long b = (long)t * TW + lane;
+    if (b >= batch) return;
+    const u64 trial = (u64)(first + b);
+    unsigned j = 0;
+    U4 r{};
+    for (int i = 0; i < omega; i++) {
+        for (;;) {
+            if ((j & 3) == 0) r = philox4x32_10(U4{j >> 2, 1u, (unsigned)trial, (unsigned)(trial >> 32)}, k0, k1);
+            const unsigned w = (j & 3) == 0 ? r.x : (j & 3) == 1 ? r.y : (j & 3) == 2 ? r.z : r.w;
+            j++;
+            const int pos = (int)__umulhi(w, (unsigned)N);
+            bool dup = false;
+            for (int q = 0; q < i; q++) dup |= chosen[q * 64 + lane] == pos;
+            if (!dup) {
+                chosen[i * 64 + lane] = pos;
+                atomicOr(planes + (size_t)t * n + pos, 1ull << lane);
+                if (out_y) out_y[(size_t)b * omega + i] = pos;
+                break;
+            }
+        }
+    }
+}
+
+// diff[t] |= OR_v (a[t][v] ^ b[t][v]) over v < nv (plane rows of stride n).  grid (ceil(nv/256), T).
+__global__ __launch_bounds__(256) void k_mc_compare(const u64 *__restrict__ a, const u64 *__restrict__ bq, int n, int nv,
+                                                    u64 *__restrict__ diff)
+{
+    const int v = blockIdx.x * 256 + threadIdx.x;
+    const int t = blockIdx.y;
+    u64 d = 0;
+    if (v < nv) d = a[(size_t)t * n + v] ^ bq[(size_t)t * n + v];
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) d |= __shfl_xor(d, off);
+    if ((threadIdx.x & 63) == 0 && d) atomicOr(diff + t, d);
+}
+
+// success[b] = !diff bit; iters passthrough.  grid T, block 64.
+__global__ __launch_bounds__(64) void k_mc_result(const u64 *__restrict__ diff, const int *__restrict__ iters, int batch,
+                                                  uint8_t *__restrict__ out_success, int *__restrict__ out_iters)
+{
+    const int t = blockIdx.x, c = threadIdx.x;
+    const long b = (long)t * TW + c;
+    if (b >= batch) return;
+    out_success[b] = (uint8_t)(((diff[t] >> c) & 1) ^ 1);
+    if (out_iters) out_iters[b] = iters[b];
+}
+
+// ---------------------------------------------------------------------------
+// Straggler compaction (early-exit runs).  Codewords are independent, so the ones a
+// group has not converged after a few iterations can be re-decoded FROM THEIR INPUTS in
+// dense tiles of their own -- bit-identical results, without dragging 64-codeword tiles
+// that are mostly finished through the remaining iterations.  These kernels move the
+// per-codeword bits / values between the original tiles and the compact ones.
+// ids[slot] = original codeword (or -1), slot_of[codeword] = compact slot (or -1).
+// ---------------------------------------------------------------------------
+// dst[t2][x] bit c2 = src[id>>6][x] bit (id&63), id = ids[64 t2 + c2].  grid (ceil(len/64), T2), block 256.
+__global__ __launch_bounds__(256) void k_gather_planes(const u64 *__restrict__ src, int len,
+                                                       const int *__restrict__ ids, u64 *__restrict__ dst)
+{
+    const int lane = threadIdx.x & 63;
+    const int x0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 16;
+    const int t2 = blockIdx.y;
+    if (x0 >= len) return;
+    const int id = ids[(size_t)t2 * TW + lane];
+    const int nx = min(16, len - x0);
+    for (int j = 0; j < nx; j++) {
+        const int bit = id >= 0 ? (int)((src[(size_t)(id >> 6) * len + x0 + j] >> (id & 63)) & 1) : 0;
+        const u64 w = __ballot(bit);
+        if (lane == 0) dst[(size_t)t2 * len + x0 + j] = w;
+    }
+}
+
+// dst[t][x] bits of the codewords with slot_of >= 0 are replaced by src2[slot>>6][x] bit (slot&63).
+// grid (ceil(len/64), T), block 256.
+__global__ __launch_bounds__(256) void k_scatter_planes(u64 *__restrict__ dst, int len,
+                                                        const int *__restrict__ slot_of,
+                                                        const u64 *__restrict__ src2)
+{
+    const int lane = threadIdx.x & 63;
+    const int x0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 16;
+    const int t = blockIdx.y;
+    if (x0 >= len) return;
+    const int sl = slot_of[(size_t)t * TW + lane];
+    const u64 mask = __ballot(sl >= 0);
+    if (mask == 0) return;
+    const int nx = min(16, len - x0);
+    for (int j = 0; j < nx; j++) {
+        const int bit = sl >= 0 ? (int)((src2[(size_t)(sl >> 6) * len + x0 + j] >> (sl & 63)) & 1) : 0;
+        const u64 w = __ballot(bit);
+        if (lane == 0) {
+            const size_t o = (size_t)t * len + x0 + j;
+            dst[o] = (dst[o] & ~mask) | (w & mask);
+        }
+    }
+}
+
+// iteration counters and converged bits back to the original positions.  grid T, block 64.
+__global__ __launch_bounds__(64) void k_scatter_state(int *__restrict__ iters, u64 *__restrict__ conv,
+                                                      const int *__restrict__ slot_of,
+                                                      const int *__restrict__ iters2, const u64 *__restrict__ conv2)
+{
+    const int t = blockIdx.x, c = threadIdx.x;
+    const int sl = slot_of[(size_t)t * TW + c];
+    if (sl >= 0) iters[(size_t)t * TW + c] = iters2[sl];
+    const int bit = sl >= 0 ? (int)((conv2[sl >> 6] >> (sl & 63)) & 1) : 0;
+    const u64 w = __ballot(bit), mask = __ballot(sl >= 0);
+    if (c == 0 && mask) conv[t] = (conv[t] & ~mask) | (w & mask);
+}
+
+// posteriors back to the original positions.  grid (n, T), block 64.
+__global__ __launch_bounds__(64) void k_scatter_post(float *__restrict__ post, int n, const int *__restrict__ slot_of,
+                                                     const float *__restrict__ post2)
+{
+    const int v = blockIdx.x, t = blockIdx.y, c = threadIdx.x;
+    const int sl = slot_of[(size_t)t * TW + c];
+    if (sl >= 0) post[((size_t)t * n + v) * TW + c] = post2[((size_t)(sl >> 6) * n + v) * TW + (sl & 63)];
+}
+
+}  // namespace

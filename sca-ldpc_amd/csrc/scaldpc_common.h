@@ -44,6 +44,10 @@ struct CacheBypass {
     bool prev;
 };
 
+// Streams of destroyed handles are parked per device and handed to the next handle created there.
+int stream_acquire(hipStream_t *out, int *device);
+void stream_release(hipStream_t s, int device);
+
 template <typename T>
 inline int dev_alloc(T **p, size_t count)
 {

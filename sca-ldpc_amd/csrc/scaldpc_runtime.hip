@@ -1,0 +1,217 @@
+// libscaldpc -- process-wide plumbing shared by the binary and the q-ary decoders: the
+// thread-local error string, the block cache behind dev_alloc / dev_free, the pool of
+// recycled streams, and the handful of C-ABI entry points that belong to no handle.
+#include "scaldpc_common.h"
+
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <unordered_map>
+#include <vector>
+
+namespace scaldpc {
+std::string &last_error()
+{
+    static thread_local std::string s;
+    return s;
+}
+int fail(int code, const char *fmt, ...)
+{
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    last_error() = buf;
+    return code;
+}
+
+// ---- block cache behind dev_alloc / dev_free (see scaldpc_common.h) ----------------------
+namespace {
+struct Block {
+    size_t bytes;
+    int device;  // -1: pinned host memory
+};
+struct BlockCache {
+    std::mutex mu;
+    std::unordered_map<void *, Block> live;       // every block handed out and still owned by a handle
+    std::vector<std::pair<void *, Block>> idle;   // released, ready for reuse
+    size_t idle_bytes = 0;
+};
+BlockCache &block_cache()
+{
+    static BlockCache *c = new BlockCache();  // never destroyed: the HIP runtime may be gone at exit
+    return *c;
+}
+constexpr size_t CACHE_BLOCK_MAX = (size_t)64 << 20, CACHE_TOTAL_MAX = (size_t)512 << 20;
+thread_local bool tl_bypass = false;  // set while serving a handle that may still have asynchronous work in flight
+bool cache_enabled()
+{
+    static const bool on = getenv("SCALDPC_NO_CACHE") == nullptr;
+    return on && !tl_bypass;
+}
+void raw_free(void *p, const Block &b)
+{
+    if (b.device < 0)
+        (void)hipHostFree(p);
+    else
+        (void)hipFree(p);
+}
+}  // namespace
+
+// SCALDPC_POISON=1 (tests): every block handed out is filled with 0xFF first, so that code
+// relying on fresh or recycled memory being zero shows up as a wrong result
+int poison(void *p, size_t bytes, bool pinned_host)
+{
+    static const bool on = getenv("SCALDPC_POISON") != nullptr;
+    if (!on) return 0;
+    if (pinned_host) {
+        memset(p, 0xFF, bytes);
+    } else {
+        SC_HIP(hipMemset(p, 0xFF, bytes));
+        SC_HIP(hipDeviceSynchronize());
+    }
+    return 0;
+}
+
+CacheBypass::CacheBypass(bool on) : prev(tl_bypass) { tl_bypass = prev || on; }
+CacheBypass::~CacheBypass() { tl_bypass = prev; }
+
+int cached_alloc(void **p, size_t bytes, bool pinned_host)
+{
+    *p = nullptr;
+    bytes = (bytes + 255) / 256 * 256;
+    int dev = -1;
+    if (!pinned_host) SC_HIP(hipGetDevice(&dev));
+    BlockCache &bc = block_cache();
+    if (cache_enabled() && bytes <= CACHE_BLOCK_MAX) {
+        std::lock_guard<std::mutex> lk(bc.mu);
+        size_t best = bc.idle.size();
+        for (size_t i = 0; i < bc.idle.size(); i++) {  // smallest block that fits without wasting more than half
+            const Block &b = bc.idle[i].second;
+            if (b.device == dev && b.bytes >= bytes && b.bytes <= 2 * bytes + 4096 &&
+                (best == bc.idle.size() || b.bytes < bc.idle[best].second.bytes))
+                best = i;
+        }
+        if (best != bc.idle.size()) {
+            *p = bc.idle[best].first;
+            bc.live.emplace(*p, bc.idle[best].second);
+            const size_t got = bc.idle[best].second.bytes;
+            bc.idle_bytes -= got;
+            bc.idle.erase(bc.idle.begin() + best);
+            return poison(*p, got, pinned_host);
+        }
+    }
+    hipError_t e = pinned_host ? hipHostMalloc(p, bytes, hipHostMallocDefault) : hipMalloc(p, bytes);
+    if (e == hipErrorOutOfMemory) {  // give the parked blocks back and try once more
+        (void)hipGetLastError();
+        scaldpc_trim();
+        e = pinned_host ? hipHostMalloc(p, bytes, hipHostMallocDefault) : hipMalloc(p, bytes);
+    }
+    if (e != hipSuccess) {
+        *p = nullptr;
+        return fail(e == hipErrorOutOfMemory ? SCALDPC_ENOMEM : SCALDPC_EHIP, "allocation of %zu bytes failed: %s", bytes,
+                    hipGetErrorString(e));
+    }
+    {
+        std::lock_guard<std::mutex> lk(bc.mu);
+        bc.live.emplace(*p, Block{bytes, dev});
+    }
+    return poison(*p, bytes, pinned_host);
+}
+
+void cached_free(void *p)
+{
+    if (!p) return;
+    BlockCache &bc = block_cache();
+    Block b{0, 0};
+    {
+        std::lock_guard<std::mutex> lk(bc.mu);
+        auto it = bc.live.find(p);
+        if (it == bc.live.end()) return;  // not ours (cannot happen through dev_free)
+        b = it->second;
+        bc.live.erase(it);
+        if (cache_enabled() && b.bytes <= CACHE_BLOCK_MAX && bc.idle_bytes + b.bytes <= CACHE_TOTAL_MAX) {
+            bc.idle.emplace_back(p, b);
+            bc.idle_bytes += b.bytes;
+            return;
+        }
+    }
+    raw_free(p, b);
+}
+
+// Streams of destroyed handles are parked per device and handed to the next handle created
+// there (creating and destroying a stream per decoder costs more than a single decode).
+struct StreamPool {
+    std::mutex mu;
+    std::vector<std::pair<int, hipStream_t>> idle;
+};
+StreamPool &stream_pool()
+{
+    static StreamPool *p = new StreamPool();  // never destroyed: the HIP runtime may be gone at exit
+    return *p;
+}
+int stream_acquire(hipStream_t *out, int *device)
+{
+    int dev = 0;
+    SC_HIP(hipGetDevice(&dev));
+    *device = dev;
+    {
+        StreamPool &sp = stream_pool();
+        std::lock_guard<std::mutex> lk(sp.mu);
+        for (size_t i = 0; i < sp.idle.size(); i++)
+            if (sp.idle[i].first == dev) {
+                *out = sp.idle[i].second;
+                sp.idle.erase(sp.idle.begin() + i);
+                return 0;
+            }
+    }
+    SC_HIP(hipStreamCreateWithFlags(out, hipStreamNonBlocking));
+    return 0;
+}
+void stream_release(hipStream_t s, int dev)
+{
+    StreamPool &sp = stream_pool();
+    std::lock_guard<std::mutex> lk(sp.mu);
+    // the handle synchronised its stream before every return, nothing is in flight
+    if (sp.idle.size() < 64) sp.idle.emplace_back(dev, s); else (void)hipStreamDestroy(s);
+}
+
+
+}  // namespace scaldpc
+
+extern "C" int scaldpc_trim(void)
+{
+    using namespace scaldpc;
+    BlockCache &bc = block_cache();
+    std::vector<std::pair<void *, Block>> drop;
+    {
+        std::lock_guard<std::mutex> lk(bc.mu);
+        drop.swap(bc.idle);
+        bc.idle_bytes = 0;
+    }
+    for (auto &d : drop) raw_free(d.first, d.second);
+    return 0;
+}
+
+using namespace scaldpc;
+
+extern "C" {
+
+const char *scaldpc_last_error(void) { return last_error().c_str(); }
+int scaldpc_version(void) { return SCALDPC_VERSION; }
+
+int scaldpc_device_count(int *count)
+{
+    if (!count) return fail(SCALDPC_EINVAL, "count is NULL");
+    SC_HIP(hipGetDeviceCount(count));
+    return 0;
+}
+
+int scaldpc_set_device(int device)
+{
+    SC_HIP(hipSetDevice(device));
+    return 0;
+}
+
+}  // extern "C"
