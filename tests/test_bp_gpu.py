@@ -407,6 +407,30 @@ def test_tile_group_size_is_invisible(group, monkeypatch):
     dec.close()
 
 
+@pytest.mark.parametrize("method", ["min_sum", "product_sum"])
+def test_stream_lanes_are_invisible(method, monkeypatch, decode_path):
+    """A tile group's tiles are dealt to stream lanes that run one kernel out of phase (two by
+    default; early-exit runs join them at every poll).  Lane count -- 1, 2, 3, 4, with even and
+    ragged groups -- cannot change a bit of the output, fixed iterations or early exit."""
+    if decode_path != "auto":
+        pytest.skip("path-independent")
+    monkeypatch.setenv("SCALDPC_PATH", "stream")
+    H, Hin, probs, msg, y = hqc_instance(499, 7, 200, 5, 0.03, 700, seed=9)
+    out = {}
+    for lanes in (1, 2, 3, 4):
+        monkeypatch.setenv("SCALDPC_SPLIT", str(lanes))
+        dec = bp.bp_decoder(H, max_iter=20, bp_method=method, channel_probs=probs)
+        for group in (4, 3):
+            dec.set_tile_group(group)
+            out[(lanes, group, "fixed")] = dec.decode_batch(msg, early_exit=False, want_llr=True)
+            out[(lanes, group, "early")] = dec.decode_batch(msg, early_exit=True, want_llr=True)
+        dec.close()
+    for key, got in out.items():
+        ref = out[(1, 4, key[2])]
+        for k in ("bits", "llr", "iters", "converged"):
+            assert np.array_equal(got[k], ref[k]), (key, k)
+
+
 def test_large_batch(oracle, monkeypatch):
     """70 000 codewords (1094 tiles) through the streaming kernels: 64-bit indexing, grid
     limits, many groups; spot-checked against the oracle, ends and middle."""
