@@ -243,41 +243,49 @@ class HqcCheckAccumulator:
         self.bp_decoder = bp_decoder
         self.max_iter = max_iter
         self.decode_every = int(decode_every)
-        self._rows = []  # sorted supports of Hin rows
-        self.checks = []  # (value, certainty)
+        self._cols = np.empty((64, self.k.size + 1), dtype=np.int32)  # row i: sorted support of Hin row i, then N + i
+        self._vals = np.empty(64, dtype=np.uint8)  # measured check values
+        self._cert = np.empty(64, dtype=np.float64)  # their certainties
+        self._R = 0
         self.decoder_stats = []
         self.num_oracle_calls = 0
         self._previous_decoding = 0
 
     def __len__(self):
-        return len(self.checks)
+        return self._R
+
+    @property
+    def checks(self):
+        """[(value, certainty)], the list simulate/hqc.py keeps (hqc.py:907)."""
+        return [(int(v), float(c)) for v, c in zip(self._vals[: self._R], self._cert[: self._R])]
 
     def add_check(self, bit_n, check, certainty):
         """hqc.py:885-908: append row `bit_n` of Hgen with its measured value."""
-        self._rows.append(np.sort((int(bit_n) - self.k) % self.N))
-        self.checks.append((int(bool(check)), float(certainty)))
+        if self._R == self._cols.shape[0]:  # amortised doubling
+            self._cols = np.concatenate([self._cols, np.empty_like(self._cols)])
+            self._vals = np.concatenate([self._vals, np.empty_like(self._vals)])
+            self._cert = np.concatenate([self._cert, np.empty_like(self._cert)])
+        row = self._cols[self._R]
+        row[:-1] = np.sort((int(bit_n) - self.k) % self.N)
+        row[-1] = self.N + self._R
+        self._vals[self._R] = int(bool(check))
+        self._cert[self._R] = float(certainty)
+        self._R += 1
 
     def graph(self):
         """H = [Hin | I_R] as a TannerGraph, built from the appended rows (never dense)."""
-        R = len(self._rows)
-        W = self.k.size
-        rows = np.repeat(np.arange(R), W + 1)
-        if R:  # each row: its W sorted circulant positions (< N), then its identity column N + i -- already CSR order
-            cols = np.concatenate([np.stack(self._rows), self.N + np.arange(R, dtype=np.int64)[:, None]], axis=1).ravel()
-        else:
-            cols = np.zeros(0, np.int64)
-        return TannerGraph(R, self.N + R, rows, cols)
+        R, W = self._R, self.k.size
+        # each row: its W sorted circulant positions (< N), then its identity column N + i -- CSR as it stands
+        return TannerGraph.from_csr(R, self.N + R, np.arange(R + 1, dtype=np.int64) * (W + 1), self._cols[:R].reshape(-1))
 
     def decode(self, y_sparse):
         """hqc.py:661-759 on the accumulated checks; appends the stats row (hqc.py:750-758)."""
-        R = len(self.checks)
+        R = self._R
         H = self.graph()
-        probs = np.concatenate(
-            [np.full(self.N, len(y_sparse) / self.N), np.array([1 - p for (_, p) in self.checks], dtype=np.float64)]
-        )
+        probs = np.concatenate([np.full(self.N, len(y_sparse) / self.N), 1 - self._cert[:R]])
         with np.errstate(divide="ignore"):
             bpd = (self.bp_decoder or _default_bp())(H, max_iter=self.max_iter, bp_method="product_sum", channel_probs=probs)
-        cvals = np.array([c for (c, _) in self.checks], dtype=np.uint8)
+        cvals = self._vals[:R].copy()
         msg = np.concatenate([np.zeros(self.N, dtype=np.uint8), cvals])
         decoded = bpd.decode_batch(msg[None, :], early_exit=True, input_vector_type="received_vector")["bits"][0]
         if hasattr(bpd, "close"):
@@ -293,7 +301,7 @@ class HqcCheckAccumulator:
         Returns True as soon as a decode succeeds, else False."""
         for bit_n, certainty in bits:
             self.add_check(bit_n, check_value, certainty)
-            R = len(self.checks)
+            R = self._R
             if self.decode_every and R % self.decode_every == 0 and self._previous_decoding != R:
                 self._previous_decoding = R
                 if self.decode(y_sparse):

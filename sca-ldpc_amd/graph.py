@@ -82,6 +82,22 @@ class TannerGraph:
 
     # -- constructors -------------------------------------------------------
     @classmethod
+    def from_csr(cls, m, n, row_ptr, col_idx, vals=None):
+        """Adopt CSR arrays as they stand (columns strictly ascending inside each row -- the
+        caller's promise; the HIP library re-validates what it is handed).  No sorting, no copies
+        beyond dtype conversion: the per-decode graph of the attack loop (hqc.py:680)."""
+        g = cls.__new__(cls)
+        g.m, g.n = int(m), int(n)
+        g.row_ptr = np.ascontiguousarray(row_ptr, dtype=np.int32)
+        g.col_idx = np.ascontiguousarray(col_idx, dtype=np.int32)
+        g.nnz = int(g.col_idx.size)
+        if g.row_ptr.shape != (g.m + 1,) or g.row_ptr[0] != 0 or g.row_ptr[-1] != g.nnz:
+            raise ValueError("row_ptr does not span [0, nnz]")
+        g.val = np.ones(g.nnz, dtype=np.int8) if vals is None else np.ascontiguousarray(vals, dtype=np.int8)
+        g._csc = None
+        return g
+
+    @classmethod
     def from_dense(cls, H):
         H = np.asarray(H)
         if H.ndim != 2:
