@@ -274,7 +274,7 @@ def qary_config4(args, S, rank, world, dist, backend, local, iters):
         dist.barrier()
     dt = time.perf_counter() - t0
     if world > 1:
-        tmax = torch.tensor([dt], dtype=torch.float64)
+        tmax = torch.tensor([dt], dtype=torch.float64, device=torch.device("cuda", local) if backend == "nccl" else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
     if rank == 0:
