@@ -830,7 +830,7 @@ int scaldpc_bp_create(int32_t m, int32_t n, int64_t nnz, const int32_t *row_ptr,
     };
     const size_t o_row_ptr = reserve((size_t)m + 1), o_col_idx = reserve((size_t)nnz), o_col_ptr = reserve((size_t)n + 1);
     const size_t o_csc_edge = reserve((size_t)nnz), o_var_list = reserve(hv.list.size());
-    const size_t o_var_meta = reserve((size_t)16 * hv.bk.blk[hv.bk.nb] + 4), o_csc_list = reserve((size_t)nnz + 1);
+    const size_t o_var_meta = reserve((size_t)4 * VAR_REC * hv.bk.blk[hv.bk.nb] + 4), o_csc_list = reserve((size_t)nnz + 1);
     const size_t o_row_list = reserve((size_t)16 * hr.bk.blk[hr.bk.nb] + 4);
     const size_t o_el_slots = reserve((size_t)el_waves * 128), o_el_winfo = reserve((size_t)el_waves * 2);
     const size_t o_prior = reserve((size_t)n);
@@ -870,16 +870,16 @@ int scaldpc_bp_create(int32_t m, int32_t n, int64_t nnz, const int32_t *row_ptr,
             md[3] = hr.bk.maxd[b];
         }
     }
-    {  // k_var: one packed descriptor per wave of the launch and the edge lists in launch order
+    {  // k_var: one record per wave of the launch (descriptor + first edges inline) and the edge lists in launch order
         int *meta = host + o_var_meta, *relaid = host + o_csc_list;
         int pos = 0;
         for (int b = 0; b < hv.bk.nb; b++) {
             const int blocks = hv.bk.blk[b + 1] - hv.bk.blk[b];
             for (int sl = 0; sl < blocks * 4; sl++) {
-                int *md = meta + 4 * ((size_t)hv.bk.blk[b] * 4 + sl);
+                int *md = meta + (size_t)VAR_REC * ((size_t)hv.bk.blk[b] * 4 + sl);
                 if (sl >= hv.bk.cnt[b]) {
                     md[0] = -1;
-                    md[1] = md[2] = md[3] = 0;
+                    for (int k = 1; k < VAR_REC; k++) md[k] = 0;
                     continue;
                 }
                 const int v = hv.list[hv.bk.off[b] + sl], d = cdeg[v];
@@ -888,6 +888,7 @@ int scaldpc_bp_create(int32_t m, int32_t n, int64_t nnz, const int32_t *row_ptr,
                 md[2] = d;
                 md[3] = hv.bk.maxd[b];
                 for (int k = 0; k < d; k++) relaid[pos + k] = csc_edge[(size_t)col_ptr[v] + k];
+                for (int k = 0; k < VAR_INLINE; k++) md[4 + k] = k < d ? relaid[pos + k] : 0;
                 pos += d;
             }
         }

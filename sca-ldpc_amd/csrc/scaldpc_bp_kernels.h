@@ -576,13 +576,19 @@ __global__ __launch_bounds__(256) void k_bp_small(const int *__restrict__ row_pt
 // exact-degree straight-line code (131 VGPRs): 68.6 vs 74.9 us).
 // Returns the posterior L.
 // ---------------------------------------------------------------------------
+// A wave's column record (VAR_REC ints, one scalar load): {column or -1, start of the column's
+// edge list in the re-laid list, degree, unroll bound, first VAR_INLINE edge ids}.
+constexpr int VAR_INLINE = 16, VAR_REC = 4 + VAR_INLINE;
+
+// ce0: the record's inline edge ids (k < VAR_INLINE), ce1: the column's full list (k beyond)
 template <int MAXD>
-__device__ __forceinline__ float var_col(float *mt, const int *__restrict__ ce, int d, float pr)
+__device__ __forceinline__ float var_col(float *mt, const int *__restrict__ ce0, const int *__restrict__ ce1, int d,
+                                         float pr)
 {
     float mm[MAXD], pp[MAXD];
 #pragma unroll
     for (int k = 0; k < MAXD; k++)
-        if (k < d) mm[k] = mt[(size_t)rfl(ce[k]) * TW];
+        if (k < d) mm[k] = mt[(size_t)rfl(k < VAR_INLINE ? ce0[k] : ce1[k]) * TW];
     float temp = pr;
 #pragma unroll
     for (int k = 0; k < MAXD; k++)
@@ -594,7 +600,7 @@ __device__ __forceinline__ float var_col(float *mt, const int *__restrict__ ce, 
 #pragma unroll
     for (int k = MAXD - 1; k >= 0; k--)
         if (k < d) {
-            mt[(size_t)rfl(ce[k]) * TW] = pp[k] + suf;
+            mt[(size_t)rfl(k < VAR_INLINE ? ce0[k] : ce1[k]) * TW] = pp[k] + suf;
             suf += mm[k];
         }
     return temp;
@@ -635,32 +641,32 @@ __global__ __launch_bounds__(256) void k_var(Buckets bk, const int *__restrict__
 {
     const int lane = threadIdx.x & 63;
     const int tl = blockIdx.y;
-    // one 16-byte descriptor per WAVE of the launch: {column or -1 (padding of a bucket's last
-    // block), start in the re-laid edge list, degree, unroll bound of the bucket}: the wave's
-    // whole prologue is this one load (walking the bucket table first cost a chain of
-    // dependent scalar loads); `csc_edge` here is the edge list laid out in launch order
-    const int4 md = ((const int4 *)list)[(size_t)blockIdx.x * 4 + (threadIdx.x >> 6)];
+    // one record per WAVE of the launch (VAR_REC ints: descriptor + the first VAR_INLINE edge ids), at
+    // an address that is plain arithmetic on the wave's index, fetched with scalar loads: the
+    // wave's whole prologue (walking the bucket table, then a descriptor, then the edge list
+    // cost a chain of dependent loads); `csc_edge` is the edge list laid out in launch order
+    const int *rec = list + (size_t)rfl((int)blockIdx.x * 4 + (int)(threadIdx.x >> 6)) * VAR_REC;
     const u64 dn = done[tl];
     if (skip_done && dn == ~0ull) return;
-    const int v = rfl(md.x);
+    const int v = rec[0];
     if (v < 0) return;
-    const int cb = rfl(md.y);
-    const int d = rfl(md.z);
+    const int cb = rec[1];
+    const int d = rec[2];
     float *mt = msg + (size_t)tl * E * TW + lane;
-    const int *ce = csc_edge + cb;
+    const int *ce = csc_edge + cb, *ce0 = rec + 4;
     const float pr = prior[v];
     float L = pr;
-    switch (rfl(md.w)) {
-        case 1: L = var_col<1>(mt, ce, d, pr); break;
-        case 2: L = var_col<2>(mt, ce, d, pr); break;
-        case 4: L = var_col<4>(mt, ce, d, pr); break;
-        case 8: L = var_col<8>(mt, ce, d, pr); break;
-        case 16: L = var_col<16>(mt, ce, d, pr); break;
+    switch (rec[3]) {
+        case 1: L = var_col<1>(mt, ce0, ce, d, pr); break;
+        case 2: L = var_col<2>(mt, ce0, ce, d, pr); break;
+        case 4: L = var_col<4>(mt, ce0, ce, d, pr); break;
+        case 8: L = var_col<8>(mt, ce0, ce, d, pr); break;
+        case 16: L = var_col<16>(mt, ce0, ce, d, pr); break;
         case 32:
-            if constexpr (CAP >= 32) L = var_col<32>(mt, ce, d, pr);
+            if constexpr (CAP >= 32) L = var_col<32>(mt, ce0, ce, d, pr);
             break;
         case 64:
-            if constexpr (CAP >= 64) L = var_col<64>(mt, ce, d, pr);
+            if constexpr (CAP >= 64) L = var_col<64>(mt, ce0, ce, d, pr);
             break;
         default: L = var_col_generic(mt, scratch + (size_t)tl * E * TW + lane, ce, d, pr);
     }
