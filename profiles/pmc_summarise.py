@@ -22,6 +22,9 @@ from collections import defaultdict
 
 
 def per_kernel(path, counter):
+    """Average per dispatch, over the dispatches of a kernel's MOST COMMON grid size: the run also
+    holds bench.py's `isolated` re-measurement, whose launches sweep the whole tile group (twice the
+    codewords of the schedule's own launches)."""
     tot, cnt = defaultdict(float), defaultdict(int)
     with open(path) as f:
         for r in csv.DictReader(f):
@@ -29,9 +32,14 @@ def per_kernel(path, counter):
                 continue
             name = re.sub(r"\(anonymous namespace\)::", "", r["Kernel_Name"])
             name = re.sub(r"^void ", "", name).split("(")[0]
-            tot[name] += float(r["Counter_Value"])
-            cnt[name] += 1
-    return {k: (tot[k] / cnt[k], cnt[k]) for k in tot}
+            key = (name, r["Grid_Size"])
+            tot[key] += float(r["Counter_Value"])
+            cnt[key] += 1
+    out = {}
+    for (name, grid), n in cnt.items():
+        if name not in out or n > out[name][1]:
+            out[name] = (tot[(name, grid)] / n, n)
+    return out
 
 
 def main():

@@ -289,7 +289,21 @@ int launch_check(scaldpc_bp *h, int method, float alpha, int G, const u64 *synd_
 #define MS_LAUNCH(W, F)                                                                                              \
     hipLaunchKernelGGL((k_check_minsum<W, F>), grid, dim3(256), 0, s, h->d_row_ptr, msg0, synd_g, done_g, skip_done, \
                        h->m, h->E, alpha, h->d_col_idx, h->d_prior)
-        if (h->max_row_deg <= ROW_CAP) {
+        const bool loop_form = getenv("SCALDPC_MINSUM_LOOP") != nullptr;  // A/B knob
+        if (h->max_row_deg <= ROW_CAP && !loop_form) {
+            dim3 gridx(h->row_bk.blk[h->row_bk.nb], G);
+#define MSX_LAUNCH(CAP, F)                                                                                          \
+    hipLaunchKernelGGL((k_check_minsum_x<CAP, F>), gridx, dim3(256), 0, s, h->d_row_list, msg0, synd_g, done_g, skip_done, \
+                       h->m, h->E, alpha, h->d_col_idx, h->d_prior)
+            if (h->max_row_deg <= 16) {
+                if (first) MSX_LAUNCH(16, true); else MSX_LAUNCH(16, false);
+            } else if (h->max_row_deg <= 32) {
+                if (first) MSX_LAUNCH(32, true); else MSX_LAUNCH(32, false);
+            } else {
+                if (first) MSX_LAUNCH(64, true); else MSX_LAUNCH(64, false);
+            }
+#undef MSX_LAUNCH
+        } else if (h->max_row_deg <= ROW_CAP) {
             if (first) MS_LAUNCH(false, true); else MS_LAUNCH(false, false);
         } else {
             if (first) MS_LAUNCH(true, true); else MS_LAUNCH(true, false);

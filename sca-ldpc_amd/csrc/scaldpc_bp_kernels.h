@@ -228,19 +228,18 @@ __global__ __launch_bounds__(256) void k_check_minsum(const int *__restrict__ ro
                                                       const int *__restrict__ col_idx, const float *__restrict__ prior)
 {
     const int lane = threadIdx.x & 63;
-    int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int r = rfl((int)blockIdx.x * 4 + (int)(threadIdx.x >> 6));  // uniform: row_ptr / synd / done go through scalar loads
     if (r >= m) return;
-    r = rfl(r);
     const int tl = blockIdx.y;
     if (skip_done && done[tl] == ~0ull) return;
-    const int e0 = rfl(row_ptr[r]);
-    const int deg = rfl(row_ptr[r + 1]) - e0;
+    const int e0 = row_ptr[r];
+    const int deg = row_ptr[r + 1] - e0;
     float *p = msg + ((size_t)tl * E + e0) * TW + lane;
     unsigned par = (unsigned)(synd[(size_t)tl * m + r] >> lane) & 1u;
     float m1 = FLT_MAX, m2 = FLT_MAX;
     int ix = 0;
     u64 neg = 0;
-#pragma unroll 8
+#pragma unroll 16
     for (int k = 0; k < deg; k++) {
         const float x = FIRST ? prior[rfl(col_idx[e0 + k])] : p[(size_t)k * TW];
         const float a = fabsf(x);
@@ -259,6 +258,67 @@ __global__ __launch_bounds__(256) void k_check_minsum(const int *__restrict__ ro
                                 : ((unsigned)(neg >> k) & 1u);
         p[(size_t)k * TW] = ((k == ix) ? m2 : m1) * ((par ^ b) ? nalpha : alpha);
     }
+}
+
+// Register-resident form for rows of degree <= 64: straight-line code instantiated for the
+// row's EXACT degree (dispatched wave-uniformly, as in k_check_tanh below): all of the row's
+// loads are issued before the first compare, the recurrences are the loop kernel's own, so the
+// results are identical.  One descriptor per wave of the launch {row or -1, first edge,
+// degree, bound} through scalar loads.  (The loop kernel keeps 8-16 loads in flight: 61.2 us
+// per 4-tile launch against this form's -- see DESIGN.md.)
+template <int DEG, bool FIRST>
+__device__ __forceinline__ void check_minsum_row(float *p, unsigned par, float alpha, const float *__restrict__ prior,
+                                                 const int *__restrict__ cidx)
+{
+    float x[DEG];
+#pragma unroll
+    for (int k = 0; k < DEG; k++) x[k] = FIRST ? prior[rfl(cidx[k])] : p[(size_t)k * TW];
+    float m1 = FLT_MAX, m2 = FLT_MAX;
+    int ix = 0;
+#pragma unroll
+    for (int k = 0; k < DEG; k++) {
+        const float a = fabsf(x[k]);
+        par ^= (unsigned)(x[k] <= 0.0f);
+        const bool lt = a < m1;
+        m2 = lt ? m1 : ((a < m2) ? a : m2);
+        ix = lt ? k : ix;
+        m1 = lt ? a : m1;
+    }
+    const float nalpha = -alpha;
+#pragma unroll
+    for (int k = 0; k < DEG; k++)
+        p[(size_t)k * TW] = ((k == ix) ? m2 : m1) * ((par ^ (unsigned)(x[k] <= 0.0f)) ? nalpha : alpha);
+}
+
+template <int CAP, bool FIRST>
+__global__ __launch_bounds__(256) void k_check_minsum_x(const int *__restrict__ list, float *msg,
+                                                        const u64 *__restrict__ synd, const u64 *__restrict__ done,
+                                                        int skip_done, int m, long E, float alpha,
+                                                        const int *__restrict__ col_idx, const float *__restrict__ prior)
+{
+    const int lane = threadIdx.x & 63;
+    const int tl = blockIdx.y;
+    const int *md = list + (size_t)rfl((int)blockIdx.x * 4 + (int)(threadIdx.x >> 6)) * 4;  // uniform address: scalar loads
+    if (skip_done && done[tl] == ~0ull) return;
+    const int r = md[0];
+    if (r < 0) return;
+    const int e0 = md[1];
+    const int deg = md[2];
+    float *p = msg + ((size_t)tl * E + e0) * TW + lane;
+    const unsigned sbit = (unsigned)(synd[(size_t)tl * m + r] >> lane) & 1u;
+#define MR(D)                                                                                   \
+    case D:                                                                                     \
+        if constexpr (D <= CAP) check_minsum_row<D, FIRST>(p, sbit, alpha, prior, col_idx + e0); \
+        break;
+#define MR8(D) MR(D) MR(D + 1) MR(D + 2) MR(D + 3) MR(D + 4) MR(D + 5) MR(D + 6) MR(D + 7)
+    switch (deg) {
+        MR(1) MR(2) MR(3) MR(4) MR(5) MR(6) MR(7)
+        MR8(8) MR8(16) MR8(24) MR8(32) MR8(40) MR8(48) MR8(56)
+        MR(64)
+        default: break;
+    }
+#undef MR8
+#undef MR
 }
 
 // ---------------------------------------------------------------------------
@@ -372,12 +432,12 @@ __global__ __launch_bounds__(256) void k_check_tanh(Buckets bk, const int *__res
     const int tl = blockIdx.y;
     // one descriptor per WAVE of the launch: {row or -1 (padding), first edge, degree, 0 = any-degree
     // fallback}: a single load instead of bucket table -> row list -> row_ptr
-    const int4 md = ((const int4 *)list)[(size_t)blockIdx.x * 4 + (threadIdx.x >> 6)];
+    const int *md = list + (size_t)rfl((int)blockIdx.x * 4 + (int)(threadIdx.x >> 6)) * 4;  // uniform address: scalar loads
     if (skip_done && done[tl] == ~0ull) return;
-    const int r = rfl(md.x);
+    const int r = md[0];
     if (r < 0) return;
-    const int e0 = rfl(md.y);
-    const int deg = rfl(md.z);
+    const int e0 = md[1];
+    const int deg = md[2];
     const size_t base = ((size_t)tl * E + e0) * TW + lane;
     float *p = msg + base;
     const unsigned sbit = (unsigned)(synd[(size_t)tl * m + r] >> lane) & 1u;
@@ -387,7 +447,7 @@ __global__ __launch_bounds__(256) void k_check_tanh(Buckets bk, const int *__res
         if constexpr (D <= CAP) check_tanh_row<D, FIRST>(p, sbit, prior, col_idx + e0);    \
         break;
 #define TR8(D) TR(D) TR(D + 1) TR(D + 2) TR(D + 3) TR(D + 4) TR(D + 5) TR(D + 6) TR(D + 7)
-    if (rfl(md.w) == 0) {
+    if (md[3] == 0) {
         check_tanh_row_generic(p, scratch + base, deg, sbit);
     } else {
         switch (deg) {
