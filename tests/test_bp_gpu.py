@@ -425,6 +425,13 @@ def test_stream_lanes_are_invisible(method, monkeypatch, decode_path):
             out[(lanes, group, "fixed")] = dec.decode_batch(msg, early_exit=False, want_llr=True)
             out[(lanes, group, "early")] = dec.decode_batch(msg, early_exit=True, want_llr=True)
         dec.close()
+    if method == "min_sum":  # the loop form of the min-sum check kernel (A/B knob; rows wider than 64 always use it)
+        monkeypatch.setenv("SCALDPC_MINSUM_LOOP", "1")
+        dec = bp.bp_decoder(H, max_iter=20, bp_method=method, channel_probs=probs)
+        dec.set_tile_group(4)
+        out[("loop", 4, "fixed")] = dec.decode_batch(msg, early_exit=False, want_llr=True)
+        out[("loop", 4, "early")] = dec.decode_batch(msg, early_exit=True, want_llr=True)
+        dec.close()
     for key, got in out.items():
         ref = out[(1, 4, key[2])]
         for k in ("bits", "llr", "iters", "converged"):
