@@ -50,7 +50,7 @@
 extern "C" {
 #endif
 
-#define SCALDPC_VERSION 100
+#define SCALDPC_VERSION 101
 
 /* status codes */
 #define SCALDPC_OK 0
