@@ -389,6 +389,42 @@ def test_device_io_equals_host_io():
             dec.close()
 
 
+def test_asynchronous_calls_on_the_callers_stream(decode_path):
+    """SCALDPC_F_ASYNC: the call only enqueues (fixed iterations, device I/O); several calls of
+    different batch sizes queue up on the caller's stream -- the second grows the handle's
+    workspace while the first may still be running -- and the caller synchronises once.  A handle
+    that went asynchronous returns its blocks through hipFree instead of parking them; creating the
+    next decoder right after close() must be safe."""
+    if decode_path != "auto":
+        pytest.skip("path-independent")
+    import torch
+
+    lib = importlib.import_module("sca-ldpc_amd._lib")
+    H, Hin, probs, msg, y = hqc_instance(997, 9, 450, 6, 0.03, 700, seed=32)
+    dec = bp.bp_decoder(H, max_iter=15, bp_method="min_sum", channel_probs=probs)
+    ref_small = dec.decode_batch(msg[:130], early_exit=False)["bits"]
+    ref_big = dec.decode_batch(msg, early_exit=False)["bits"]
+    dec.close()
+    dec = bp.bp_decoder(H, max_iter=15, bp_method="min_sum", channel_probs=probs)
+    st = torch.cuda.Stream()
+    with torch.cuda.stream(st):
+        d_in = torch.from_numpy(msg).cuda()
+        outs = [torch.zeros((b, H.n), dtype=torch.uint8, device="cuda") for b in (130, 700, 130)]
+        for o in outs:
+            dec.decode_batch_device(d_in.data_ptr(), lib.IN_RECEIVED, o.shape[0], o.data_ptr(), early_exit=False,
+                                    stream=st.cuda_stream, asynchronous=True)
+    st.synchronize()
+    assert np.array_equal(outs[0].cpu().numpy(), ref_small) and np.array_equal(outs[2].cpu().numpy(), ref_small)
+    assert np.array_equal(outs[1].cpu().numpy(), ref_big)
+    with pytest.raises(ValueError, match="ASYNC"):  # early exit polls the device: cannot be asynchronous
+        dec.decode_batch_device(d_in.data_ptr(), lib.IN_RECEIVED, 130, outs[0].data_ptr(), early_exit=True,
+                                stream=st.cuda_stream, asynchronous=True)
+    dec.close()
+    dec = bp.bp_decoder(H, max_iter=15, bp_method="min_sum", channel_probs=probs)
+    assert np.array_equal(dec.decode_batch(msg[:130], early_exit=False)["bits"], ref_small)
+    dec.close()
+
+
 @pytest.mark.parametrize("group", [1, 2, 5])
 def test_tile_group_size_is_invisible(group, monkeypatch):
     """Results cannot depend on how tiles are grouped for cache residency (ragged last group,

@@ -126,6 +126,27 @@ def test_graph_roundtrip(scaldpc):
     assert np.array_equal(gi.to_dense(), np.concatenate([H, np.eye(7, dtype=int)], axis=1))
 
 
+def test_graph_constructors_agree(scaldpc):
+    """Entries handed over in CSR order skip the sort, `from_csr` adopts arrays as they stand, the CSC
+    view is built on first use: all three must describe the same graph as the sorting constructor fed
+    a shuffled edge list; duplicates and bad spans are still refused."""
+    rng = np.random.RandomState(8)
+    H = (rng.rand(40, 90) < 0.12).astype(int)
+    r, c = np.nonzero(H)  # row-major: already CSR order
+    p = rng.permutation(r.size)
+    a = scaldpc.TannerGraph(40, 90, r[p], c[p])  # sorts
+    b = scaldpc.TannerGraph(40, 90, r, c)  # fast path
+    d = scaldpc.TannerGraph.from_csr(40, 90, a.row_ptr, a.col_idx)
+    for g in (b, d):
+        for f in ("row_ptr", "col_idx", "val", "col_ptr", "csc_edge", "csc_row"):
+            assert np.array_equal(getattr(g, f), getattr(a, f)), f
+        assert np.array_equal(g.to_dense(), H)
+    with pytest.raises(ValueError, match="duplicate"):
+        scaldpc.TannerGraph(2, 3, [0, 0, 1], [1, 1, 2])
+    with pytest.raises(ValueError, match="row_ptr"):
+        scaldpc.TannerGraph.from_csr(2, 3, [0, 1, 5], [0, 1])
+
+
 def test_rep_code(scaldpc):
     g = scaldpc.codes.rep_code_graph(13)
     H = g.to_dense()
