@@ -112,7 +112,14 @@ struct scaldpc_bp {
     size_t cap_el_unsat = 0;
     int *d_el_slots = nullptr, *d_el_winfo = nullptr;  // k_el_var: columns packed into waves of 64 lane slots
     int el_waves = 0;
-    int *d_graph = nullptr;  // ONE allocation behind every graph array above and d_prior (views into it)
+    int *d_graph = nullptr;  // ONE allocation behind the arrays every path needs (CSR, CSC, var list, d_prior: views into it)
+    // The tables only one kernel family reads are built on that family's first use -- a decoder
+    // that lives for one single decode (hqc.py:694) never pays for the tile kernels' tables, a
+    // benchmark never for the row-parallel ones.  What the builders need stays on the host:
+    int *d_tile_tab = nullptr;  // row descriptors, k_var records, re-laid edge list (d_row_list, d_var_meta, d_csc_list)
+    int *d_el_tab = nullptr;    // k_el_var slots and wave info (d_el_slots, d_el_winfo)
+    std::vector<int> hg_row_ptr, hg_cdeg, hg_col_ptr, hg_csc_edge;
+    HostBuckets hg_var, hg_row;
     int stat_el = 0;  // codewords the row-parallel kernels decoded in the last call
     int identity_from = -1;  // n - m if the last m columns of H are I_m (H = [Hin | I]), else -1
     hipStream_t own_stream = nullptr;
@@ -225,9 +232,139 @@ int ensure_workspace(scaldpc_bp *h, int T, int G, bool want_post, int max_iter)
     return 0;
 }
 
+// Host staging buffer for table uploads, reused by the thread's later constructions (fresh pages
+// for a multi-megabyte vector cost more page-fault time than filling it).  Not cleared.
+int *stage_buffer(size_t ints)
+{
+    struct Staging {
+        int *p = nullptr;
+        size_t cap = 0;
+        ~Staging() { free(p); }
+    };
+    static thread_local Staging stage;
+    if (ints > stage.cap || stage.cap > ((size_t)64 << 20)) {  // (and do not sit on more than 256 MB)
+        free(stage.p);
+        stage.cap = 0;
+        stage.p = (int *)malloc(std::max<size_t>(ints, 1) * sizeof(int));
+        if (!stage.p) return nullptr;
+        stage.cap = ints;
+    }
+    return stage.p;
+}
+
+int upload_table(int **dst, const int *host, size_t ints)
+{
+    SC_TRY(dev_alloc(dst, ints));
+    SC_HIP(hipMemcpy(*dst, host, ints * sizeof(int), hipMemcpyHostToDevice));
+    return 0;
+}
+
+// Tables of the 64-codeword-tile kernels: one descriptor per wave of a check launch, one record per
+// wave of a k_var launch (descriptor + first edges inline), the edge lists in launch order.
+int ensure_tile_tables(scaldpc_bp *h)
+{
+    if (h->d_tile_tab) return 0;
+    const HostBuckets &hv = h->hg_var, &hr = h->hg_row;
+    const int *row_ptr = h->hg_row_ptr.data(), *cdeg = h->hg_cdeg.data(), *col_ptr = h->hg_col_ptr.data(),
+              *csc_edge = h->hg_csc_edge.data();
+    size_t total = 0;
+    auto reserve = [&](size_t cnt) {
+        const size_t off = total;
+        total += (cnt + 63) / 64 * 64;
+        return off;
+    };
+    const size_t o_var_meta = reserve((size_t)4 * VAR_REC * hv.bk.blk[hv.bk.nb] + 4), o_csc_list = reserve((size_t)h->E + 1);
+    const size_t o_row_list = reserve((size_t)16 * hr.bk.blk[hr.bk.nb] + 4);
+    int *host = stage_buffer(total);
+    if (!host) return fail(SCALDPC_ENOMEM, "out of host memory");
+    for (int b = 0; b < hr.bk.nb; b++) {
+        const int blocks = hr.bk.blk[b + 1] - hr.bk.blk[b];
+        for (int sl = 0; sl < blocks * 4; sl++) {
+            int *md = host + o_row_list + 4 * ((size_t)hr.bk.blk[b] * 4 + sl);
+            const bool pad = sl >= hr.bk.cnt[b];
+            const int r = pad ? -1 : hr.list[hr.bk.off[b] + sl];
+            md[0] = r;
+            md[1] = pad ? 0 : row_ptr[r];
+            md[2] = pad ? 0 : row_ptr[r + 1] - row_ptr[r];
+            md[3] = hr.bk.maxd[b];
+        }
+    }
+    int *meta = host + o_var_meta, *relaid = host + o_csc_list;
+    int pos = 0;
+    for (int b = 0; b < hv.bk.nb; b++) {
+        const int blocks = hv.bk.blk[b + 1] - hv.bk.blk[b];
+        for (int sl = 0; sl < blocks * 4; sl++) {
+            int *md = meta + (size_t)VAR_REC * ((size_t)hv.bk.blk[b] * 4 + sl);
+            if (sl >= hv.bk.cnt[b]) {
+                md[0] = -1;
+                for (int k = 1; k < VAR_REC; k++) md[k] = 0;
+                continue;
+            }
+            const int v = hv.list[hv.bk.off[b] + sl], d = cdeg[v];
+            md[0] = v;
+            md[1] = pos;
+            md[2] = d;
+            md[3] = hv.bk.maxd[b];
+            for (int k = 0; k < d; k++) relaid[pos + k] = csc_edge[(size_t)col_ptr[v] + k];
+            for (int k = 0; k < VAR_INLINE; k++) md[4 + k] = k < d ? relaid[pos + k] : 0;
+            pos += d;
+        }
+    }
+    SC_TRY(upload_table(&h->d_tile_tab, host, total));
+    h->d_var_meta = h->d_tile_tab + o_var_meta;
+    h->d_csc_list = h->d_tile_tab + o_csc_list;
+    h->d_row_list = h->d_tile_tab + o_row_list;
+    return 0;
+}
+
+// Tables of the row-parallel path: whole columns, in degree order, packed into waves of 64 lane slots.
+int ensure_el_tables(scaldpc_bp *h)
+{
+    if (h->d_el_tab || h->el_waves == 0) return 0;
+    const HostBuckets &hv = h->hg_var;
+    const int *cdeg = h->hg_cdeg.data(), *col_ptr = h->hg_col_ptr.data(), *csc_edge = h->hg_csc_edge.data();
+    const size_t o_slots = 0, o_winfo = ((size_t)h->el_waves * 128 + 63) / 64 * 64, total = o_winfo + (size_t)h->el_waves * 2;
+    int *host = stage_buffer(total);
+    if (!host) return fail(SCALDPC_ENOMEM, "out of host memory");
+    int *slots = host + o_slots, *winfo = host + o_winfo;
+    int w = -1, used = 64;
+    auto pad_wave = [&]() {  // empty slots: no edge, not valid
+        if (w >= 0)
+            for (; used < 64; used++) {
+                slots[2 * ((size_t)w * 64 + used)] = -1;
+                slots[2 * ((size_t)w * 64 + used) + 1] = 0;
+            }
+    };
+    for (size_t i = 0; i < hv.list.size(); i++) {
+        const int v = hv.list[i], d = cdeg[v], need = std::max(d, 1);
+        if (used + need > 64) {
+            pad_wave();
+            w++;
+            used = 0;
+            winfo[2 * w + 0] = 0;
+            winfo[2 * w + 1] = (int)i;
+        }
+        winfo[2 * w] = std::max(winfo[2 * w], d);
+        const int *ce = csc_edge + col_ptr[v];
+        int *sl = slots + 2 * ((size_t)w * 64 + used);
+        const int tag = used | (d << 13) | (1 << 20);
+        for (int k = 0; k < need; k++) {
+            sl[2 * k] = d ? ce[k] : -1;
+            sl[2 * k + 1] = tag | (k << 6);
+        }
+        used += need;
+    }
+    pad_wave();
+    SC_TRY(upload_table(&h->d_el_tab, host, total));
+    h->d_el_slots = h->d_el_tab + o_slots;
+    h->d_el_winfo = h->d_el_tab + o_winfo;
+    return 0;
+}
+
 // message array of the tile path, G tiles
 int ensure_msg(scaldpc_bp *h, int G)
 {
+    SC_TRY(ensure_tile_tables(h));
     if (G > h->cap_group) {
         dev_free(h->d_msg); dev_free(h->d_scratch);
         h->cap_group = 0;
@@ -241,6 +378,7 @@ int ensure_msg(scaldpc_bp *h, int G)
 // message + prefix arrays of the row-parallel path, nb codewords
 int ensure_el(scaldpc_bp *h, int nb)
 {
+    SC_TRY(ensure_el_tables(h));
     const size_t need = (size_t)nb * h->E;
     if (need > h->cap_el || !h->d_emsg) {
         dev_free(h->d_emsg);
@@ -814,28 +952,20 @@ int scaldpc_bp_create(int32_t m, int32_t n, int64_t nnz, const int32_t *row_ptr,
         h->identity_from = ident ? n - m : -1;
     }
 
-    // Every device-side graph array is a view into ONE allocation filled by ONE copy: the
-    // attack loop builds a new decoder per decode (hqc.py:694), so construction is on its
-    // critical path (a dozen hipMalloc + synchronous hipMemcpy pairs cost more than the decode).
-    const bool el = nnz > 0 && h->max_row_deg <= 64 && h->max_col_deg <= 64;
-    int el_waves = 0;
-    if (el) {  // row-parallel path: whole columns, in degree order, packed into waves of 64 lane slots
-        int used = 0;
+    // The arrays every path needs are views into ONE allocation filled by ONE copy: the attack loop
+    // builds a new decoder per decode (hqc.py:694), so construction is on its critical path (a dozen
+    // hipMalloc + synchronous hipMemcpy pairs cost more than the decode).  The per-kernel-family
+    // tables follow on first use (ensure_tile_tables / ensure_el_tables).
+    if (nnz > 0 && h->max_row_deg <= 64 && h->max_col_deg <= 64) {  // row-parallel path possible: count its waves
+        int used = 0, el_waves = 0;
         for (size_t i = 0; i < hv.list.size(); i++) {
             const int need = std::max(cdeg[hv.list[i]], 1);
             if (used + need > 64) used = 0;
             if (used == 0) el_waves++;
             used += need;
         }
+        h->el_waves = el_waves;
     }
-    // host staging buffer, reused by the thread's later constructions (fresh pages for a
-    // 5 MB vector cost more page-fault time than everything else here)
-    struct Staging {
-        int *p = nullptr;
-        size_t cap = 0;
-        ~Staging() { free(p); }
-    };
-    static thread_local Staging stage;
     size_t total = 0;
     auto reserve = [&](size_t cnt) {  // 256-byte aligned sections
         const size_t off = total;
@@ -844,21 +974,12 @@ int scaldpc_bp_create(int32_t m, int32_t n, int64_t nnz, const int32_t *row_ptr,
     };
     const size_t o_row_ptr = reserve((size_t)m + 1), o_col_idx = reserve((size_t)nnz), o_col_ptr = reserve((size_t)n + 1);
     const size_t o_csc_edge = reserve((size_t)nnz), o_var_list = reserve(hv.list.size());
-    const size_t o_var_meta = reserve((size_t)4 * VAR_REC * hv.bk.blk[hv.bk.nb] + 4), o_csc_list = reserve((size_t)nnz + 1);
-    const size_t o_row_list = reserve((size_t)16 * hr.bk.blk[hr.bk.nb] + 4);
-    const size_t o_el_slots = reserve((size_t)el_waves * 128), o_el_winfo = reserve((size_t)el_waves * 2);
     const size_t o_prior = reserve((size_t)n);
-    if (total > stage.cap) {
-        free(stage.p);
-        stage.cap = 0;
-        stage.p = (int *)malloc(total * sizeof(int));
-        if (!stage.p) {
-            delete h;
-            return fail(SCALDPC_ENOMEM, "out of host memory");
-        }
-        stage.cap = total;
+    int *const host = stage_buffer(total);  // not cleared: every word a kernel reads is written below
+    if (!host) {
+        delete h;
+        return fail(SCALDPC_ENOMEM, "out of host memory");
     }
-    int *const host = stage.p;  // not cleared: every word a kernel reads is written below
     TMARK("reserve");
     std::copy(row_ptr, row_ptr + m + 1, host + o_row_ptr);
     std::copy(col_idx, col_idx + nnz, host + o_col_idx);
@@ -870,86 +991,20 @@ int scaldpc_bp_create(int32_t m, int32_t n, int64_t nnz, const int32_t *row_ptr,
         std::vector<int> cursor(col_ptr, col_ptr + n);
         for (int e = 0; e < (int)nnz; e++) csc_edge[cursor[col_idx[e]]++] = e;
     }
-    TMARK("csc");
     std::copy(hv.list.begin(), hv.list.end(), host + o_var_list);
-    for (int b = 0; b < hr.bk.nb; b++) {  // k_check_tanh: one descriptor per wave of the launch
-        const int blocks = hr.bk.blk[b + 1] - hr.bk.blk[b];
-        for (int sl = 0; sl < blocks * 4; sl++) {
-            int *md = host + o_row_list + 4 * ((size_t)hr.bk.blk[b] * 4 + sl);
-            const bool pad = sl >= hr.bk.cnt[b];
-            const int r = pad ? -1 : hr.list[hr.bk.off[b] + sl];
-            md[0] = r;
-            md[1] = pad ? 0 : row_ptr[r];
-            md[2] = pad ? 0 : rdeg[r];
-            md[3] = hr.bk.maxd[b];
-        }
-    }
-    {  // k_var: one record per wave of the launch (descriptor + first edges inline) and the edge lists in launch order
-        int *meta = host + o_var_meta, *relaid = host + o_csc_list;
-        int pos = 0;
-        for (int b = 0; b < hv.bk.nb; b++) {
-            const int blocks = hv.bk.blk[b + 1] - hv.bk.blk[b];
-            for (int sl = 0; sl < blocks * 4; sl++) {
-                int *md = meta + (size_t)VAR_REC * ((size_t)hv.bk.blk[b] * 4 + sl);
-                if (sl >= hv.bk.cnt[b]) {
-                    md[0] = -1;
-                    for (int k = 1; k < VAR_REC; k++) md[k] = 0;
-                    continue;
-                }
-                const int v = hv.list[hv.bk.off[b] + sl], d = cdeg[v];
-                md[0] = v;
-                md[1] = pos;
-                md[2] = d;
-                md[3] = hv.bk.maxd[b];
-                for (int k = 0; k < d; k++) relaid[pos + k] = csc_edge[(size_t)col_ptr[v] + k];
-                for (int k = 0; k < VAR_INLINE; k++) md[4 + k] = k < d ? relaid[pos + k] : 0;
-                pos += d;
-            }
-        }
-    }
-    TMARK("meta");
-    if (el) {
-        int *slots = host + o_el_slots, *winfo = host + o_el_winfo;
-        int w = -1, used = 64;
-        auto pad_wave = [&]() {  // empty slots: no edge, not valid
-            if (w >= 0)
-                for (; used < 64; used++) {
-                    slots[2 * ((size_t)w * 64 + used)] = -1;
-                    slots[2 * ((size_t)w * 64 + used) + 1] = 0;
-                }
-        };
-        for (size_t i = 0; i < hv.list.size(); i++) {
-            const int v = hv.list[i], d = cdeg[v], need = std::max(d, 1);
-            if (used + need > 64) {
-                pad_wave();
-                w++;
-                used = 0;
-                winfo[2 * w + 0] = 0;
-                winfo[2 * w + 1] = (int)i;
-            }
-            winfo[2 * w] = std::max(winfo[2 * w], d);
-            const int *ce = csc_edge + col_ptr[v];
-            int *sl = slots + 2 * ((size_t)w * 64 + used);
-            const int tag = used | (d << 13) | (1 << 20);
-            for (int k = 0; k < need; k++) {
-                sl[2 * k] = d ? ce[k] : -1;
-                sl[2 * k + 1] = tag | (k << 6);
-            }
-            used += need;
-        }
-        pad_wave();
-        h->el_waves = el_waves;
-    }
-    TMARK("slots");
+    TMARK("csc");
     int rc = dev_alloc(&h->d_graph, total);
     if (!rc && hipMemcpy(h->d_graph, host, total * sizeof(int), hipMemcpyHostToDevice) != hipSuccess)
         rc = fail(SCALDPC_EHIP, "graph upload failed");
-    if (stage.cap > ((size_t)64 << 20)) {  // do not sit on more than 256 MB
-        free(stage.p);
-        stage.p = nullptr;
-        stage.cap = 0;
-    }
     TMARK("upload");
+    // what the lazy table builders need
+    h->hg_row_ptr.assign(row_ptr, row_ptr + m + 1);
+    h->hg_col_ptr.assign(col_ptr, col_ptr + n + 1);
+    h->hg_csc_edge.assign(csc_edge, csc_edge + nnz);
+    h->hg_cdeg.swap(cdeg);
+    h->hg_var = std::move(hv);
+    h->hg_row = std::move(hr);
+    TMARK("keep");
     if (!rc) rc = stream_acquire(&h->own_stream, &h->device);
     TMARK("stream");
     if (rc) {
@@ -961,11 +1016,6 @@ int scaldpc_bp_create(int32_t m, int32_t n, int64_t nnz, const int32_t *row_ptr,
     h->d_col_ptr = h->d_graph + o_col_ptr;
     h->d_csc_edge = h->d_graph + o_csc_edge;
     h->d_var_list = h->d_graph + o_var_list;
-    h->d_var_meta = h->d_graph + o_var_meta;
-    h->d_csc_list = h->d_graph + o_csc_list;
-    h->d_row_list = h->d_graph + o_row_list;
-    h->d_el_slots = h->d_graph + o_el_slots;
-    h->d_el_winfo = h->d_graph + o_el_winfo;
     h->d_prior = (float *)(h->d_graph + o_prior);
     *out = h;
     return 0;
@@ -1423,6 +1473,8 @@ void scaldpc_bp_destroy(scaldpc_bp *h)
 {
     if (!h) return;
     dev_free(h->d_graph);  // graph arrays and d_prior are views into it
+    dev_free(h->d_tile_tab);
+    dev_free(h->d_el_tab);
     dev_free(h->d_msg); dev_free(h->d_scratch); dev_free(h->d_post);
     dev_free(h->d_synd); dev_free(h->d_recv); dev_free(h->d_hard); dev_free(h->d_done);
     dev_free(h->d_conv); dev_free(h->d_unsat); dev_free(h->d_iters); dev_free(h->d_remaining);
