@@ -31,6 +31,7 @@
 #define RTANH tanh
 #define RABS fabs
 #define RBIG 1e308
+#define RTINY 0.0 /* no flush in the float64 instantiation */
 #include "bp_oracle_impl.h"
 #undef REAL
 #undef SFX
@@ -40,6 +41,7 @@
 #undef RTANH
 #undef RABS
 #undef RBIG
+#undef RTINY
 
 #define REAL float
 #define SFX f32
@@ -49,6 +51,7 @@
 #define RTANH tanhf
 #define RABS fabsf
 #define RBIG FLT_MAX
+#define RTINY FLT_MIN /* method 3 mirrors the kernel: reciprocals below FLT_MIN are flushed (hardware v_rcp_f32) */
 #include "bp_oracle_impl.h"
 #undef REAL
 #undef SFX
@@ -58,6 +61,7 @@
 #undef RTANH
 #undef RABS
 #undef RBIG
+#undef RTINY
 
 /*
  * Batch front end with the `decode(v)` input convention of the reference's

@@ -23,7 +23,10 @@
  *             u_k = 1 - tanh(|x_k|/2) = 2/(exp|x_k| + 1); exclusive products kept as
  *             U = 1 - prod(1-u) through U' = fma(u, 1-U, U); |c2v| = log(2/U - 1).
  *             Same function as methods 0/2, but free of the 1-x cancellation that
- *             makes the textbook form saturate at |L| ~ 17 in fp32.
+ *             makes the textbook form saturate at |L| ~ 17 in fp32.  The f32 instance
+ *             also mirrors the hardware reciprocal's flush of results / operands below
+ *             FLT_MIN, i.e. where in the narrow band 87.3 < |L| < 88.7 a message turns
+ *             infinite.
  *
  * Parity status: pinned for HARD DECISIONS by the reference's three doctests
  * (decode.py:139-149; hqc.py:1229-1274; hqc.py:1277-1311) -- see
@@ -99,7 +102,11 @@ int FN(oracle_bp_decode)(int m, int n, const int32_t *row_ptr, const int32_t *co
                 for (int e = row_ptr[i]; e < row_ptr[i + 1]; e++) {
                     c2b[e] = U;
                     esgn[e] = sgn;
-                    const REAL u = (REAL)2 / (REXP(RABS(b2c[e])) + (REAL)1);
+                    /* the kernel forms 2 * rcp(e^|x| + 1) on the hardware reciprocal unit, which
+                     * returns 0 for results below FLT_MIN (|x| > 87.3): mirrored in the f32 instance */
+                    REAL rc = (REAL)1 / (REXP(RABS(b2c[e])) + (REAL)1);
+                    if (rc < (REAL)RTINY) rc = (REAL)0;
+                    const REAL u = (REAL)2 * rc;
                     ubuf[e] = u;
                     U = RFMA(u, (REAL)1 - U, U);
                     if (b2c[e] < (REAL)0) sgn += 1;
@@ -109,7 +116,8 @@ int FN(oracle_bp_decode)(int m, int n, const int32_t *row_ptr, const int32_t *co
                 for (int e = row_ptr[i + 1] - 1; e >= row_ptr[i]; e--) {
                     const REAL Ut = RFMA(U, (REAL)1 - c2b[e], c2b[e]);
                     esgn[e] += sgn;
-                    const REAL Lm = RLOG((REAL)2 / Ut - (REAL)1);
+                    /* ... and takes a denormal operand for 0: 1/Ut = inf, |c2v| = inf */
+                    const REAL Lm = (Ut < (REAL)RTINY) ? (REAL)INFINITY : RLOG(RFMA((REAL)2, (REAL)1 / Ut, (REAL)-1));
                     c2b[e] = (esgn[e] & 1) ? -Lm : Lm;
                     U = RFMA(ubuf[e], (REAL)1 - U, U);
                     if (b2c[e] < (REAL)0) sgn += 1;
