@@ -3,6 +3,7 @@ alphabets Q in {3, 5, 7}, pmfs with zero-probability symbols (+inf LLRs), ragged
 (covers the unrolled, wave-parallel and lane-per-codeword kernels) -- hard decisions
 bit-exact with the oracle."""
 import importlib
+import os
 
 import numpy as np
 import pytest
@@ -15,7 +16,8 @@ pytestmark = pytest.mark.gpu
 qary = importlib.import_module("sca-ldpc_amd.qary")
 
 
-@settings(max_examples=30, deadline=None, derandomize=True, suppress_health_check=list(HealthCheck))
+@settings(max_examples=int(os.environ.get("SCALDPC_PROPERTY_EXAMPLES", "30")), deadline=None, derandomize=True,
+          suppress_health_check=list(HealthCheck))
 @given(R=st.integers(2, 10), N=st.integers(6, 24), dc=st.integers(2, 5), B=st.integers(1, 3),
        batch=st.sampled_from([1, 3, 40, 70, 300]), iters=st.integers(1, 6), seed=st.integers(0, 9999),
        zero_frac=st.sampled_from([0.0, 0.1]))
