@@ -15,10 +15,29 @@ pytestmark = pytest.mark.gpu
 bp = importlib.import_module("sca-ldpc_amd.bp")
 
 
+def _own_sensitivity(oracle, g, probs, x, kind, max_iter, method, early, ref):
+    """20x the largest relative move of the oracle's posteriors between float32 and float64 (same
+    operation order), never below the fixed fp32 tolerance 2e-4."""
+    tol = 2e-4
+    if method == "product_sum":
+        with np.errstate(divide="ignore", invalid="ignore"):
+            ref64 = oracle.bp_decode_batch(g, probs, x, kind, max_iter, ORACLE_METHOD[method], dtype="f64", threads=8,
+                                           early_exit=early)
+            same = ref64["iters"] == ref["iters"]
+            own = np.abs(ref64["llr"][same] - ref["llr"][same]) / (1.0 + np.abs(ref["llr"][same]))
+        own = own[np.isfinite(own)]
+        if own.size:
+            tol = max(tol, 20.0 * float(own.max()))
+    return tol
+
+
 @settings(max_examples=int(os.environ.get("SCALDPC_PROPERTY_EXAMPLES", "60")), deadline=None, derandomize=True,
           suppress_health_check=list(HealthCheck))
 @given(
-    m=st.integers(1, 40), n=st.integers(2, 80), density=st.floats(0.02, 0.5), batch=st.integers(1, 140),
+    # (density stops at 0.35: denser graphs with m >> n push non-settling BP into the saturation band
+    # 87.3 < |L| < 88.7, where a 1-ulp difference decides between a finite message and an infinite one
+    # and, two iterations later, between a number and inf - inf)
+    m=st.integers(1, 40), n=st.integers(2, 80), density=st.floats(0.02, 0.35), batch=st.integers(1, 140),
     method=st.sampled_from(["min_sum", "product_sum"]), received=st.booleans(), early=st.booleans(),
     path=st.sampled_from(["auto", "stream", "edge"]), max_iter=st.integers(1, 24), seed=st.integers(0, 10_000),
     inf_priors=st.booleans(), lanes=st.integers(1, 3), group=st.integers(0, 2),
@@ -27,12 +46,17 @@ def test_random_instances(oracle, m, n, density, batch, method, received, early,
                           group):
     if m == n:
         n += 1  # square H needs an explicit input type; covered elsewhere
+    if method == "product_sum":
+        max_iter = min(max_iter, 10)  # see the note on chaotic amplification below; min-sum is exact at any length
     rng = np.random.RandomState(seed)
     H = (rng.rand(m, n) < density).astype(np.int8)
     g = S.TannerGraph.from_dense(H)
     probs = rng.uniform(0.005, 0.3, size=n)
     if inf_priors:
         probs[rng.rand(n) < 0.15] = 0.0
+        # infinite priors feed infinities into the chaotic regime described below, where after a dozen
+        # iterations a 1-ulp difference decides which infinity wins (+inf, -inf or their NaN sum)
+        max_iter = min(max_iter, 8)
     err = (rng.rand(batch, n) < np.maximum(probs, 0.02)[None, :]).astype(np.uint8)
     x = err if received else g.syndrome(err)
     if path == "auto":
@@ -58,13 +82,51 @@ def test_random_instances(oracle, m, n, density, batch, method, received, early,
     # scales with what the oracle itself moves when the same operation order runs in double: the
     # device may deviate from the f32 oracle by 20x that, and never gets less than the fixed fp32
     # tolerance the LDPC-shaped tests use.
-    tol = 2e-4
-    if method == "product_sum":
-        with np.errstate(divide="ignore", invalid="ignore"):
-            ref64 = oracle.bp_decode_batch(g, probs, x, 1 if received else 0, max_iter, ORACLE_METHOD[method],
-                                           dtype="f64", threads=4, early_exit=early)
-            own = np.abs(ref64["llr"] - ref["llr"]) / (1.0 + np.abs(ref["llr"]))
-        own = own[np.isfinite(own)]
-        if own.size:
-            tol = max(tol, 20.0 * float(own.max()))
-    compare(got, ref, method, stuck_tol=tol)
+    compare(got, ref, method, stuck_tol=_own_sensitivity(oracle, g, probs, x, 1 if received else 0, max_iter, method, early, ref),
+            tie_codewords=1 + batch // 64)
+
+
+@settings(max_examples=int(os.environ.get("SCALDPC_PROPERTY_EXAMPLES", "24")), deadline=None, derandomize=True,
+          suppress_health_check=list(HealthCheck))
+@given(
+    N=st.integers(700, 2500), W=st.integers(5, 13), rfrac=st.floats(0.3, 0.6), omega=st.integers(3, 12),
+    eps=st.sampled_from([0.0, 0.02, 0.05]), batch=st.integers(1, 330),
+    method=st.sampled_from(["min_sum", "product_sum"]), early=st.booleans(),
+    path=st.sampled_from(["auto", "stream", "edge"]), max_iter=st.integers(2, 40), seed=st.integers(0, 10_000),
+    lanes=st.integers(1, 3), group=st.integers(0, 3), compact_after=st.sampled_from([None, 0, 2, 4]),
+)
+def test_random_hqc_shaped_instances(oracle, N, W, rfrac, omega, eps, batch, method, early, path, max_iter, seed, lanes,
+                                     group, compact_after):
+    """HQC-shaped graphs [Hin | I] too large for LDS (the tile kernels, the row-parallel kernels, the
+    compaction levels and the stream lanes all come into play): random size, row weight, check count,
+    noise (incl. certainty-1.0 checks), batch, iteration budget, scheduling knobs.  Bit-exact for
+    min-sum.  Tanh rule: the sweep reaches corners no decoder is meant for (row weight 5 against a
+    secret of weight 12 in 700 positions: nothing converges, 38 iterations of chaotic wandering), so
+    the tolerance is the oracle-sensitivity one of the test above; on the BASELINE-like parameters of
+    tests/test_bp_gpu.py the fixed tolerance holds without it."""
+    from helpers import hqc_instance
+
+    R = max(20, int(N * rfrac))
+    H, Hin, probs, msg, y = hqc_instance(N, W, R, omega, eps, batch, seed=seed)
+    env = {"SCALDPC_SPLIT": str(lanes)}
+    if path != "auto":
+        env["SCALDPC_PATH"] = path
+    if compact_after is not None:
+        env["SCALDPC_COMPACT_AFTER"] = str(compact_after)
+    keys = ("SCALDPC_SPLIT", "SCALDPC_PATH", "SCALDPC_COMPACT_AFTER")
+    try:
+        for k in keys:
+            os.environ.pop(k, None)
+        os.environ.update(env)
+        with np.errstate(divide="ignore"):
+            dec = bp.bp_decoder(H, max_iter=max_iter, bp_method=method, channel_probs=probs)
+            dec.set_tile_group(group)
+            got = dec.decode_batch(msg, early_exit=early, want_llr=True)
+            dec.close()
+            ref = oracle.bp_decode_batch(H, probs, msg, 1, max_iter, ORACLE_METHOD[method], dtype="f32", threads=8,
+                                         early_exit=early)
+    finally:
+        for k in keys:
+            os.environ.pop(k, None)
+    compare(got, ref, method, stuck_tol=_own_sensitivity(oracle, H, probs, msg, 1, max_iter, method, early, ref),
+            tie_codewords=1 + batch // 64)
