@@ -39,7 +39,7 @@ def hqc_instance(N, W, R, omega, eps, batch, seed, flip=True):
 ORACLE_METHOD = {"min_sum": "min_sum", "product_sum": "tanh_complement"}
 
 
-def compare(got, ref, method, llr_rtol=2e-4, llr_atol=2e-4, stuck_tol=None, tie_codewords=0):
+def compare(got, ref, method, llr_rtol=2e-4, llr_atol=2e-4, widened_tol=None, tie_codewords=0):
     """HIP result vs the f32 oracle instantiation that runs the same operation order.
 
     min-sum  : everything bit-exact -- hard decisions, iteration counts, converged
@@ -53,11 +53,11 @@ def compare(got, ref, method, llr_rtol=2e-4, llr_atol=2e-4, stuck_tol=None, tie_
                converge (with certainty-1.0 checks a stuck trial collapses many
                messages to exactly 0), so their number is bounded only on the
                CONVERGED trials, where a tie would be a real disagreement.
-               stuck_tol (the property test on tiny dense graphs only): BP that does not settle
+               widened_tol (the property test on tiny dense graphs only): BP that does not settle
                on a graph full of 4-cycles is a chaotic map -- it amplifies the 1-ulp
                differences of exp / log 2-3x per iteration (and runs into inf - inf = NaN on
                both sides) -- so that test holds every posterior to
-               |dL| <= stuck_tol * (1 + |L|), with stuck_tol derived from how far the oracle
+               |dL| <= widened_tol * (1 + |L|), with widened_tol derived from how far the oracle
                itself moves between float32 and float64 (never below 2e-4).  The tests on
                LDPC-like graphs (sparse, HQC-shaped, the BASELINE sizes) never relax anything.
     """
@@ -93,8 +93,8 @@ def compare(got, ref, method, llr_rtol=2e-4, llr_atol=2e-4, stuck_tol=None, tie_
     assert np.array_equal(np.isnan(a), np.isnan(b)), "NaN posteriors (inf - inf) in different places"
     fin = ~np.isnan(b)
     tol_all = llr_atol + llr_rtol * np.abs(b)
-    if stuck_tol is not None:
-        tol_all = stuck_tol * (1.0 + np.abs(b))
+    if widened_tol is not None:
+        tol_all = widened_tol * (1.0 + np.abs(b))
     assert (np.abs(a[fin] - b[fin]) <= tol_all[fin]).all(), "posterior outside the fp32 tolerance"
     with np.errstate(invalid="ignore"):
         decided = fin & (np.abs(b) > tol_all)
@@ -102,7 +102,7 @@ def compare(got, ref, method, llr_rtol=2e-4, llr_atol=2e-4, stuck_tol=None, tie_
     conv = ref["converged"].astype(bool)
     # (not in the property tests: a widened tolerance widens the tie band with it, and with p = 0
     # priors on odd little graphs whole trials collapse to exact zeros whatever their flag says)
-    if stuck_tol is None and not tie_codewords:
+    if widened_tol is None and not tie_codewords:
         assert (~decided)[conv].sum() <= max(3, 1e-3 * decided[conv].size), "ties on converged trials"
 
 
