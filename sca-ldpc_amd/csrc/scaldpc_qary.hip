@@ -24,7 +24,11 @@
 // roofline claim is made for it.
 #include "scaldpc_common.h"
 
+#include <chrono>
+
 #include <cmath>
+#include <condition_variable>
+#include <functional>
 #include <cstring>
 #include <mutex>
 #include <thread>
@@ -699,6 +703,68 @@ int growq(T **p, size_t *cap, size_t need)
 // decoder.rs:668-692 on the host with glibc logf -- bit-identical to the oracle (and to what
 // the reference's f32::ln gives on the same platform).  One logf per symbol is the dominant
 // host cost of a large batch, so codewords are split over host threads.
+// A few persistent host threads for the probability -> LLR conversion (spawning sixteen threads per
+// call cost a third of the conversion at config-4 size).  One job at a time (callers serialise on
+// the pool's mutex); workers are detached and live as long as the process.
+class HostPool {
+  public:
+    static HostPool &get()
+    {
+        static HostPool *p = new HostPool();
+        return *p;
+    }
+    // runs fn(0) ... fn(n - 1), fn(0) on the calling thread
+    void run(int n, const std::function<void(int)> &fn)
+    {
+        if (n <= 1) {
+            fn(0);
+            return;
+        }
+        std::lock_guard<std::mutex> job(job_mu_);
+        {
+            std::unique_lock<std::mutex> lk(mu_);
+            while ((int)workers_ < n - 1) {
+                const int id = workers_++;
+                std::thread([this, id] { loop(id); }).detach();
+            }
+            fn_ = &fn;
+            n_ = n;
+            pending_ = n - 1;
+            epoch_++;
+        }
+        cv_.notify_all();
+        fn(0);
+        std::unique_lock<std::mutex> lk(mu_);
+        done_.wait(lk, [this] { return pending_ == 0; });
+        fn_ = nullptr;
+    }
+
+  private:
+    void loop(int id)
+    {
+        unsigned long seen = 0;
+        for (;;) {
+            const std::function<void(int)> *fn;
+            {
+                std::unique_lock<std::mutex> lk(mu_);
+                cv_.wait(lk, [&] { return epoch_ != seen; });
+                seen = epoch_;
+                if (id + 1 >= n_) continue;  // this job needs fewer workers
+                fn = fn_;
+            }
+            (*fn)(id + 1);
+            std::unique_lock<std::mutex> lk(mu_);
+            if (--pending_ == 0) done_.notify_one();
+        }
+    }
+    std::mutex job_mu_, mu_;
+    std::condition_variable cv_, done_;
+    const std::function<void(int)> *fn_ = nullptr;
+    int n_ = 0, pending_ = 0;
+    unsigned workers_ = 0;
+    unsigned long epoch_ = 0;
+};
+
 int host_into_llr(const float *pmf, int batch, int nv, int Q, long Bp, long row0, float *llr)
 {
     const size_t work = (size_t)batch * nv * Q;
@@ -735,19 +801,25 @@ int host_into_llr(const float *pmf, int batch, int nv, int Q, long Bp, long row0
                 }
                 for (int q = 0; q < Q; q++) {
                     float *dst = llr + ((size_t)(row0 + (long)v * Q + q)) * Bp + b0;
-                    for (int i = 0; i < nb; i++) dst[i] = logf(mx[i] / pmf[((size_t)(b0 + i) * nv + v) * Q + q]);
+                    // measured channel outputs repeat a handful of pmf rows (decode.py:232-237 has two):
+                    // remember the last (max, p) -> ln(max / p) and skip the division and the logf when the
+                    // next codeword brings the same pair (same function, same result)
+                    float lm = -1.0f, lp = -1.0f, lv = 0.0f;
+                    for (int i = 0; i < nb; i++) {
+                        const float pv = pmf[((size_t)(b0 + i) * nv + v) * Q + q];
+                        if (!(pv == lp && mx[i] == lm)) {
+                            lm = mx[i];
+                            lp = pv;
+                            lv = logf(lm / lp);
+                        }
+                        dst[i] = lv;
+                    }
                     for (int i = nb; i < 64; i++) dst[i] = 0.0f;  // padding lanes: all-equal messages
                 }
             }
         }
     };
-    if (nthreads == 1) {
-        worker(0);
-    } else {
-        std::vector<std::thread> th;
-        for (int t = 0; t < nthreads; t++) th.emplace_back(worker, t);
-        for (auto &t : th) t.join();
-    }
+    HostPool::get().run(nthreads, worker);
     int first = -1;
     for (int t = 0; t < nthreads; t++)
         if (bad_b[t] >= 0 && (first < 0 || bad_b[t] < bad_b[first] || (bad_b[t] == bad_b[first] && bad_v[t] < bad_v[first])))
@@ -792,7 +864,11 @@ int qary_run(scaldpc_qary *h, const float *pmf_b, const float *pmf_s, int batch,
             SC_TRY(cached_alloc((void **)&h->h_llr, need * sizeof(float), true));
             h->cap_h_llr = need;
         }
+        const auto t0__ = std::chrono::steady_clock::now();
         SC_TRY(host_into_llr(pmf_b, batch, BV, h->Q, Bp, 0, h->h_llr));
+        if (getenv("SCALDPC_TIMING"))
+            fprintf(stderr, "[qary] into_llr %.1f us\n",
+                    std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0__).count());
         if (h->special) SC_TRY(host_into_llr(pmf_s, batch, h->R, h->QS, Bp, (long)BV * h->Q, h->h_llr));
         SC_HIP(hipMemcpyAsync(h->d_llr, h->h_llr, need * sizeof(float), hipMemcpyHostToDevice, s));
     } else {
