@@ -1026,12 +1026,19 @@ int scaldpc_bp_set_channel_probs(scaldpc_bp *h, const double *probs)
     if (!h || !probs) return fail(SCALDPC_EINVAL, "NULL argument");
     std::lock_guard<std::mutex> lk(h->mu);
     std::vector<float> llr(h->n);
+    float last_p = 0.0f, last_llr = 0.0f;
     for (int j = 0; j < h->n; j++) {
         if (!(probs[j] >= 0.0 && probs[j] <= 1.0))
             return fail(SCALDPC_EINVAL, "channel_probs[%d] = %g is not a probability", j, probs[j]);
         // same expression, in fp32, as the oracle's f32 instantiation: log((1-p)/p)
+        // (priors come in long runs of one value -- [w/N]*N ++ [1-certainty]*R, hqc.py:686-691 --
+        // so the previous result is reused while p repeats)
         const float p = (float)probs[j];
-        llr[j] = logf((1.0f - p) / p);
+        if (j == 0 || p != last_p) {
+            last_p = p;
+            last_llr = logf((1.0f - p) / p);
+        }
+        llr[j] = last_llr;
     }
     SC_HIP(hipMemcpy(h->d_prior, llr.data(), sizeof(float) * h->n, hipMemcpyHostToDevice));
     h->h_probs.assign(probs, probs + h->n);
