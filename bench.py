@@ -204,7 +204,7 @@ def main():
             "kernel_ms": {"check_per_launch": ms_check, "var_pass": ms_var_pass},
             "hbm_copy_ceiling_GBps": copy_gbs,  # measured: 1 GiB device copy, read+write bytes/s
         }
-        kname = "k_check_minsum" if dominant_is_check else "k_check_tanh"
+        kname = "k_check_minsum_x" if dominant_is_check else "k_check_tanh"
         traffic = pmc_traffic(args.workload, batch, swept, "k_check_minsum" if dominant_is_check else "k_check_tanh")
         # Two-lane schedule: the dominant kernel never runs alone -- each stream alternates check and
         # variable launches over its half of the tile group, one kernel out of phase with the other
