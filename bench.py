@@ -20,6 +20,8 @@ import argparse
 import importlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -61,7 +63,12 @@ def main():
     ap.add_argument("--mc-batch", type=int, default=32768, help="hqc128_mc: trials per device call (the stragglers "
                     "of one call share its compact second pass, so larger is better: 190k/229k/240k trials/s at "
                     "4096/16384/65536)")
+    ap.add_argument("--rendezvous-only", action="store_true", help="launch, rendezvous, one all_gather of the rank "
+                    "ids, print {rccl_ranks}; no decode (checks the N>1 launch path; works over gloo without a GPU)")
+    ap.add_argument("--parity-rows", type=int, default=64, help="codewords of the timed output checked against the "
+                    "CPU oracle after the timed region (0 = skip); a mismatch makes the run exit non-zero")
     args = ap.parse_args()
+    self_launch(args)
 
     import torch
     import torch.distributed as dist
@@ -70,7 +77,9 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.rendezvous_only:
+        return rendezvous_only(args, torch, dist, rank, world, local)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback in the product path)")
     # Rehearsal knobs (one-GPU box only): several ranks on one device over gloo.  The real
@@ -243,6 +252,49 @@ def main():
     dec.close()
     if world > 1:
         dist.destroy_process_group()
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` from a plain shell (N > 1, no RANK in the environment): start the
+    N ranks as a CHILD `python -m torch.distributed.run ... bench.py <same arguments>` -- one process
+    per GPU over RCCL, rendezvous on 127.0.0.1 -- forward its output and exit with its return code.
+    This runs before torch is imported or any HIP call is made: a process that has touched the GPU
+    is never replaced or re-executed.  (The reference's only parallelism is a pool of independent
+    decode calls, simulate/decode.py:247-262, and a shell loop over independent runs,
+    run-parallel-hqc-simulation.sh:10-43: nothing to coordinate but the launch.)"""
+    if args.gpus <= 1 or "RANK" in os.environ:
+        return
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL across processes needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", "1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.stdout.flush()
+    raise SystemExit(subprocess.run(cmd, env=env).returncode)
+
+
+def rendezvous_only(args, torch, dist, rank, world, local):
+    """The N > 1 launch path without the decode: process group up, one all_gather of the rank ids (the
+    same collective the end-of-run gather uses), rank 0 prints what it saw."""
+    backend = os.environ.get("BENCH_BACKEND", "nccl")
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    dev = None
+    if backend == "nccl":
+        torch.cuda.set_device(int(os.environ.get("BENCH_FORCE_DEVICE", local)))
+        dev = torch.device("cuda", torch.cuda.current_device())
+    if world > 1:
+        dist.init_process_group(backend, rank=rank, world_size=world)
+    shard = importlib.import_module("sca-ldpc_amd.shard")
+    seen = shard.gather_results(np.array([rank], dtype=np.int32), world, rank, world, device=dev)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps({"rendezvous_only": True, "n_gpus": world, "backend": backend, "rccl_ranks": int(len(set(seen.tolist())))}),
+              flush=True)
 
 
 def qary_config4(args, S, rank, world, dist, backend, local, iters):

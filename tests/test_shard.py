@@ -76,3 +76,39 @@ def test_two_rank_gloo_matches_single_process():
     single = _decode_range(0, total)
     assert np.array_equal(full, single)
     assert 0 < single.sum() < total  # both outcomes present
+
+
+def _run_bench(*argv, **env):
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    e = dict(os.environ, **env)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        e.pop(k, None)  # a plain shell, as the driver's `python3 bench.py --gpus N`
+    return subprocess.run([sys.executable, os.path.join(root, "bench.py"), *argv], env=e, capture_output=True, text=True,
+                          timeout=600)
+
+
+def test_bench_launches_its_own_ranks_from_a_plain_shell():
+    """`python bench.py --gpus 2` without torchrun around it must start the two ranks itself (as a child
+    process, before anything touches a GPU), rendezvous on 127.0.0.1 and run the end-of-run collective;
+    rank 0's line reports how many ranks the all_gather saw."""
+    import json
+
+    r = _run_bench("--gpus", "2", "--rendezvous-only", BENCH_BACKEND="gloo")
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["rccl_ranks"] == 2 and line["backend"] == "gloo"
+
+
+def test_bench_forwards_its_childrens_failure():
+    """No GPU here: the ranks refuse to run (no CPU fallback in the product path) and the launcher's
+    exit code says so -- the self-launch must not swallow a failed rank."""
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("needs a machine without a GPU")
+    r = _run_bench("--gpus", "2", "--steps", "1", "--warmup", "0", BENCH_BACKEND="gloo")
+    assert r.returncode != 0
+    assert "needs a GPU" in (r.stderr + r.stdout)
