@@ -63,12 +63,22 @@ def main():
     ap.add_argument("--mc-batch", type=int, default=32768, help="hqc128_mc: trials per device call (the stragglers "
                     "of one call share its compact second pass, so larger is better: 190k/229k/240k trials/s at "
                     "4096/16384/65536)")
+    ap.add_argument("--pmc", choices=["live", "file", "off"], default="live", help="roofline.traffic: 'live' = two short "
+                    "rocprofv3 --pmc child runs (FETCH_SIZE, WRITE_SIZE) of this very workload before the timed run "
+                    "(N=1 only; falls back to 'file'), 'file' = the committed profiles/*_pmc_traffic_*.json, 'off' = null")
+    ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)  # the short run the PMC passes profile
+    ap.add_argument("--no-hbm-streaming", action="store_true", help="skip the extra pass with tile groups far beyond "
+                    "the Infinity Cache (roofline.hbm_streaming_GBps)")
     ap.add_argument("--rendezvous-only", action="store_true", help="launch, rendezvous, one all_gather of the rank "
                     "ids, print {rccl_ranks}; no decode (checks the N>1 launch path; works over gloo without a GPU)")
     ap.add_argument("--parity-rows", type=int, default=64, help="codewords of the timed output checked against the "
                     "CPU oracle after the timed region (0 = skip); a mismatch makes the run exit non-zero")
     args = ap.parse_args()
     self_launch(args)
+    # PMC passes first: children of a process that has not touched the GPU yet
+    live_traffic = None
+    if args.gpus == 1 and args.pmc == "live" and not args.pmc_child and WORKLOADS[args.workload][0] and args.workload != "hqc128_mc":
+        live_traffic = pmc_live(args.workload)
 
     import torch
     import torch.distributed as dist
@@ -112,6 +122,8 @@ def main():
 
     if args.workload == "hqc128_mc":
         return mc_sweep(args, S, bp, lib, trials, H, N, omega, R, E, probs, iters, method, rank, world, local, dist, backend)
+    if args.pmc_child:  # what the PMC passes profile: one cache-resident group's worth of launches, nothing else
+        iters = 6
     dec = bp.bp_decoder(H, max_iter=iters, bp_method=method, channel_probs=probs)
     if args.tile_group:
         dec.set_tile_group(args.tile_group)
@@ -131,6 +143,13 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    if args.pmc_child:
+        step()
+        fence()
+        kt = dec.time_kernels(1, stream=stream)
+        print(json.dumps({"pmc_child": True, "codewords_per_launch": kt["codewords"], "lanes": kt["lanes"]}), flush=True)
+        dec.close()
+        return
     for _ in range(args.warmup):
         step()
     fence()
@@ -144,6 +163,25 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
 
+    # the same kernels streaming from HBM: one tile group = the whole batch (far beyond the 256 MiB
+    # Infinity Cache), same launches otherwise -- the other regime next to the cache-resident one
+    hbm_stream = None
+    if not args.no_hbm_streaming and rank == 0 and world == 1:
+        T = (batch + 63) // 64
+        dec.set_tile_group(T)
+        step()
+        fence()
+        t1 = time.perf_counter()
+        for _ in range(2):
+            step()
+        fence()
+        ht = (time.perf_counter() - t1) / 2
+        hbm_stream = {"GBps": 16.0 * E * iters * batch / ht / 1e9, "ms_per_step": ht * 1e3,
+                      "group_MB": 4.0 * E * 64 * T / 1e6}
+        dec.set_tile_group(args.tile_group)
+        step()  # leave the default schedule's state behind for the kernel timing below
+        fence()
+
     # per-kernel launch durations, HIP events on the launch stream
     kt = dec.time_kernels(50, stream=stream)
     ms_check = kt["ms_check"] / max(1, kt["launches_check"])
@@ -152,9 +190,9 @@ def main():
     lanes = kt["lanes"]  # 2: timed in the decode's own two-stream launch pattern (one event per launch)
     iso = None
     if lanes == 2:  # the same kernels alone on the chip, one series after the other over the whole tile group
-        os.environ["SCALDPC_SPLIT"] = "1"
+        dec.configure(split=1)
         iso = dec.time_kernels(50, stream=stream)
-        del os.environ["SCALDPC_SPLIT"]
+        dec.configure(split=2)
 
     # measured device copy ceiling on this very GPU (SURVEY.md 8d asks for it next to the
     # datasheet peak): 1 GiB float copy, read + write bytes / time
@@ -173,19 +211,21 @@ def main():
 
     # success statistics + the one end-of-run collective
     shard = importlib.import_module("sca-ldpc_amd.shard")
-    ok = trials.success(d_out.cpu().numpy(), ys, N).astype(np.uint8)
+    out_host = d_out.cpu().numpy()
+    ok = trials.success(out_host, ys, N).astype(np.uint8)
     ok_all = shard.gather_results(ok, batch * world, rank, world, device=dev if backend == "nccl" else None)  # RCCL all_gather
+    ranks_seen = shard.gather_results(np.array([rank], dtype=np.int32), world, rank, world, device=dev if backend == "nccl" else None)
     succ = float(ok_all.mean())
     conv = float(d_conv.float().mean().item())
 
+    rc = 0
     if rank == 0:
         total_cw = batch * world * args.steps
         updates = 2.0 * E * iters * total_cw
         value = updates / dt
-        algo_bytes_per_check_launch = 8.0 * E * swept  # 4 B read + 4 B written per edge per codeword
-        check_gbs = algo_bytes_per_check_launch / (ms_check * 1e-3) / 1e9
+        check_gbs = 8.0 * E * swept / (ms_check * 1e-3) / 1e9  # 4 B read + 4 B written per edge per codeword
         var_gbs = 8.0 * E * kt["codewords_var"] / (ms_var_pass * 1e-3) / 1e9
-        dominant_is_check = method == "min_sum"
+        cname = "k_check_minsum_x" if method == "min_sum" else "k_check_tanh"
         out = {
             "metric": "edge_message_updates_per_s",
             "value": value,
@@ -206,6 +246,7 @@ def main():
                 "eps": args.eps,
                 "tile_group": args.tile_group,
             },
+            "rccl_ranks": int(len(set(ranks_seen.tolist()))),  # ranks the end-of-run all_gather saw
             "codewords_per_s": total_cw / dt,
             "whole_job_algorithmic_GBps": 16.0 * E * iters * total_cw / dt / 1e9,
             "decode_success_rate": succ,
@@ -213,45 +254,160 @@ def main():
             "kernel_ms": {"check_per_launch": ms_check, "var_pass": ms_var_pass},
             "hbm_copy_ceiling_GBps": copy_gbs,  # measured: 1 GiB device copy, read+write bytes/s
         }
-        kname = "k_check_minsum_x" if dominant_is_check else "k_check_tanh"
-        traffic = pmc_traffic(args.workload, batch, swept, "k_check_minsum" if dominant_is_check else "k_check_tanh")
-        # Two-lane schedule: the dominant kernel never runs alone -- each stream alternates check and
+        # The kernel with the larger share of GPU time is the dominant one (k_var on every workload so
+        # far).  Under the two-lane schedule no kernel runs alone: each stream alternates check and
         # variable launches over its half of the tile group, one kernel out of phase with the other
-        # stream -- so the rate that belongs next to the HBM peak is the chip's: both lanes'
-        # algorithmic bytes per (check + variable) launch pair over the pair's duration
-        # (DESIGN.md section 5).  `per_launch` holds each kernel's own in-situ launch duration, which
-        # is what rocprofv3 reports for it; `isolated` the same kernels alone on the chip.
-        if lanes == 2:
-            achieved = 2.0 * (8.0 * E * swept + 8.0 * E * kt["codewords_var"]) / ((ms_check + ms_var_pass) * 1e-3) / 1e9
-        else:
-            achieved = check_gbs
+        # stream, so `achieved` is the CHIP's algorithmic rate over a (check + variable) launch pair:
+        # lanes x (bytes of a check launch + bytes of a variable launch) / (t_check + t_var)
+        # (DESIGN.md section 5).  `per_launch` = each kernel's in-situ launch duration (what rocprofv3
+        # reports for it), `dominant` = the larger one, `isolated` = the same kernels alone on the chip.
+        # The messages of a tile group are served by the 256 MiB Infinity Cache by design (the group is
+        # sized for it), which is why `achieved` can exceed what HBM streaming sustains
+        # (`hbm_copy_ceiling_GBps`, `hbm_streaming_GBps`); `peak` stays the HBM datasheet figure the
+        # contract names.
+        dom_is_var = ms_var_pass >= ms_check
+        dname = "k_var" if dom_is_var else cname
+        achieved = lanes * (8.0 * E * swept + 8.0 * E * kt["codewords_var"]) / ((ms_check + ms_var_pass) * 1e-3) / 1e9
+        traffic, traffic_src = None, None
+        if live_traffic and live_traffic.get("codewords_per_launch") == swept:
+            tk = live_traffic["kernels"].get("k_var" if dom_is_var else ("k_check_minsum" if method == "min_sum" else "k_check_tanh"))
+            if tk:
+                traffic, traffic_src = tk["traffic_bytes"], "live rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this run"
+        if traffic is None and args.pmc != "off":
+            traffic = pmc_traffic(args.workload, batch, swept, "k_var" if dom_is_var else ("k_check_minsum" if method == "min_sum" else "k_check_tanh"))
+            traffic_src = "profiles/ (committed PMC passes of this geometry)" if traffic is not None else None
         out["roofline"] = {
-            "bound": "hbm",
-            "kernel": kname if lanes == 1 else f"{kname} (two streams: co-running with k_var / {kname} of the other half of the tile group)",
+            "bound": "infinity-cache",  # what serves the bytes; the contract's class for this path is "hbm" (no MFMA)
+            "bound_class": "hbm",
+            "kernel": dname,
             "achieved": achieved,
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS,
             "traffic": traffic,
+            "traffic_source": traffic_src,
+            "algorithmic_bytes_per_launch": 8.0 * E * (kt["codewords_var"] if dom_is_var else swept),
             "lanes": lanes,
+            "dominant": {"name": dname, "us": (ms_var_pass if dom_is_var else ms_check) * 1e3,
+                         "share_of_pair_time": max(ms_var_pass, ms_check) / (ms_check + ms_var_pass),
+                         "algorithmic_GBps": var_gbs if dom_is_var else check_gbs,
+                         # alone on the chip (one lane: its own rate; two lanes: filled in from `isolated` below)
+                         "frac": (var_gbs if dom_is_var else check_gbs) / HBM_PEAK_GBS if lanes == 1 else None},
             "per_launch": {
-                kname: {"codewords": swept, "us": ms_check * 1e3, "algorithmic_GBps": check_gbs},
+                cname: {"codewords": swept, "us": ms_check * 1e3, "algorithmic_GBps": check_gbs},
                 "k_var": {"codewords": kt["codewords_var"], "us": ms_var_pass * 1e3, "algorithmic_GBps": var_gbs},
             },
+            "hbm_streaming_GBps": hbm_stream["GBps"] if hbm_stream else None,
+            "hbm_streaming": hbm_stream,
         }
+        if live_traffic:
+            out["roofline"]["traffic_all_kernels"] = live_traffic["kernels"]
         if iso:
             ic = iso["ms_check"] / max(1, iso["launches_check"])
             iv = iso["ms_var"] / max(1, iso["launches_var"])
+            ig = {cname: 8.0 * E * iso["codewords"] / (ic * 1e-3) / 1e9, "k_var": 8.0 * E * iso["codewords_var"] / (iv * 1e-3) / 1e9}
             out["roofline"]["isolated"] = {
-                kname: {"codewords": iso["codewords"], "us": ic * 1e3, "algorithmic_GBps": 8.0 * E * iso["codewords"] / (ic * 1e-3) / 1e9},
-                "k_var": {"codewords": iso["codewords_var"], "us": iv * 1e3, "algorithmic_GBps": 8.0 * E * iso["codewords_var"] / (iv * 1e-3) / 1e9},
+                cname: {"codewords": iso["codewords"], "us": ic * 1e3, "algorithmic_GBps": ig[cname]},
+                "k_var": {"codewords": iso["codewords_var"], "us": iv * 1e3, "algorithmic_GBps": ig["k_var"]},
             }
+            out["roofline"]["dominant"]["frac"] = ig[dname] / HBM_PEAK_GBS  # the dominant kernel alone on the chip
+        if args.parity_rows > 0:
+            out.update(parity_check(H, probs, msg, out_host, iters, method, min(args.parity_rows, batch)))
+            rc = 0 if out["parity_ok"] else 3
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(H, probs, msg, iters, method, E, args.cpu_seconds)
         print(json.dumps(out), flush=True)
     dec.close()
     if world > 1:
         dist.destroy_process_group()
+    if rc:
+        raise SystemExit(rc)
+
+
+def parity_check(H, probs, msg, out_host, iters, method, rows):
+    """After the timed region: the first `rows` codewords of the timed output against the CPU oracle
+    (f32, same operation order; test infrastructure, never part of what is timed).  min-sum: every bit
+    equal.  tanh rule: bits equal wherever the oracle's posterior is outside the fp32 tolerance of
+    tests/helpers.compare (|L| > 2e-4 + 2e-4 |L|)."""
+    from oracle import pyoracle
+
+    om = {"min_sum": "min_sum", "product_sum": "tanh_complement"}[method]
+    threads = max(1, min(os.cpu_count() or 1, pyoracle.max_threads(), rows))
+    ref = pyoracle.bp_decode_batch(H, probs, msg[:rows], 1, iters, om, dtype="f32", threads=threads, early_exit=False)
+    diff = out_host[:rows] != ref["bits"]
+    if method != "min_sum":
+        with np.errstate(invalid="ignore"):
+            diff &= np.abs(ref["llr"]) > 2e-4
+    return {"parity_checked": int(rows), "parity_mismatched_bits": int(diff.sum()), "parity_ok": bool(not diff.any()),
+            "parity_against": f"oracle f32 {om}, {iters} fixed iterations, first {rows} codewords of the timed output"}
+
+
+def pmc_live(workload):
+    """roofline.traffic measured in THIS run: two rocprofv3 passes (FETCH_SIZE and WRITE_SIZE do not fit
+    one) of `bench.py --pmc-child` -- the same workload, one 256-codeword slice (the launch geometry of
+    the timed run: a cache-resident tile group per lane), 6 iterations -- started as child processes
+    BEFORE this process touches the GPU.  Units and gfx950 corrections as MI355X_MICROARCH.md's HBM
+    section prescribes (KiB; FETCH_SIZE x2: 128-byte read requests are tallied at 64 B; WRITE_SIZE x1;
+    re-verified on profiles/microbench/rmw_stream).  These are L2 <-> fabric bytes: Infinity-Cache hits
+    are counted, so they bound HBM bytes from above.  Returns None if anything goes wrong."""
+    import csv
+    import re
+    import shutil
+    import tempfile
+    from collections import defaultdict
+
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe) or "rocprof" in os.environ.get("LD_PRELOAD", "") or os.environ.get("ROCPROFILER_REGISTER_FORCE_LOAD"):
+        return None  # no profiler, or this process is itself being profiled
+    env = dict(os.environ, TMPDIR="/tmp")
+    per = {}
+    geom = None
+    with tempfile.TemporaryDirectory(dir="/tmp") as td:
+        for counter, scale in (("FETCH_SIZE", 2048.0), ("WRITE_SIZE", 1024.0)):
+            cmd = [exe, "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", os.path.join(td, counter), "-o", "p",
+                   "--", sys.executable, os.path.abspath(__file__), "--pmc-child", "--workload", workload, "--batch", "256",
+                   "--no-cpu-baseline", "--pmc", "off", "--parity-rows", "0"]
+            try:
+                r = subprocess.run(cmd, env=env, cwd="/tmp", capture_output=True, text=True, timeout=420)
+            except Exception:
+                return None
+            if r.returncode != 0:
+                return None
+            for ln in r.stdout.splitlines():
+                if ln.startswith("{") and "pmc_child" in ln:
+                    geom = json.loads(ln)
+            path = None
+            for root, _, files in os.walk(os.path.join(td, counter)):
+                for f in files:
+                    if f.endswith("counter_collection.csv"):
+                        path = os.path.join(root, f)
+            if not path:
+                return None
+            tot, cnt = defaultdict(float), defaultdict(int)
+            with open(path) as fh:
+                for row in csv.DictReader(fh):
+                    if row["Counter_Name"] != counter:
+                        continue
+                    name = re.sub(r"^void ", "", row["Kernel_Name"].replace("(anonymous namespace)::", "")).split("(")[0]
+                    if not name.startswith(("k_var", "k_check")) or name.endswith("true>"):
+                        continue  # (FIRST = true: the first iteration reads the priors, not the messages)
+                    base = name.split("<")[0]
+                    key = (base[:-2] if base.endswith("_x") else base, row["Grid_Size"])
+                    tot[key] += float(row["Counter_Value"]) * scale
+                    cnt[key] += 1
+            best = {}
+            for (name, grid), n in cnt.items():  # the most common grid = the schedule's own launches
+                if name not in best or n > best[name][1]:
+                    best[name] = (tot[(name, grid)] / n, n)
+            for name, (b, n) in best.items():
+                per.setdefault(name, {})[counter] = b
+                per[name]["dispatches"] = n
+    if not geom or not per:
+        return None
+    kernels = {k: {"fetch_bytes": v.get("FETCH_SIZE"), "write_bytes": v.get("WRITE_SIZE"),
+                   "traffic_bytes": (v.get("FETCH_SIZE") or 0.0) + (v.get("WRITE_SIZE") or 0.0), "dispatches": v["dispatches"]}
+               for k, v in per.items() if "FETCH_SIZE" in v and "WRITE_SIZE" in v}
+    return {"codewords_per_launch": geom["codewords_per_launch"], "kernels": kernels}
 
 
 def self_launch(args):
@@ -409,7 +565,7 @@ def pmc_traffic(workload, batch, swept, kernel):
             # `kernel`: name prefix; the steady-state instantiation is the one whose last template
             # argument (FIRST: inputs are the priors) is false
             for name, v in d["kernels"].items():
-                if name.startswith(kernel) and name.endswith("false>"):
+                if name.startswith(kernel) and not name.endswith("true>"):
                     return v["traffic_bytes"]
     except Exception:
         pass

@@ -23,6 +23,8 @@
  *                                simulate_rs/src/pydecoder.rs:24-45 -> simulate_rs/src/decoder.rs:494-553
  *   scaldpc_qary_min_sum_batch   PyO3 `min_sum`, simulate_rs/src/pydecoder.rs:53-65
  *                                -> decoder.rs:668-692 (into_llr) + decoder.rs:560-666 (min_sum)
+ *   scaldpc_qary_into_llr        Decoder::into_llr, simulate_rs/src/decoder.rs:668-692 (== decoder_special.rs:619-643),
+ *                                the conversion alone (its known-answer test: decoder.rs:744-768)
  *   scaldpc_qary_special_create / _min_sum_batch
  *                                simulate_rs/src/pydecoder.rs:96-117,125-145
  *                                -> simulate_rs/src/decoder_special.rs:387-464, 471-617
@@ -50,7 +52,7 @@
 extern "C" {
 #endif
 
-#define SCALDPC_VERSION 101
+#define SCALDPC_VERSION 102
 
 /* status codes */
 #define SCALDPC_OK 0
@@ -139,6 +141,24 @@ int scaldpc_bp_last_compacted(scaldpc_bp *h, int64_t *count);
  *            compacted again, up to 3 levels)
  *   out[3] = reserved (0) */
 int scaldpc_bp_last_stats(scaldpc_bp *h, int64_t *out);
+/* Tuning / test knobs of one handle.  A new handle takes its defaults from the environment ONCE, at
+ * creation (SCALDPC_PATH, SCALDPC_SPLIT, SCALDPC_GROUP_MB, SCALDPC_EL_MAX, SCALDPC_EL_FUSE,
+ * SCALDPC_COMPACT_AFTER, SCALDPC_MINSUM_LOOP, SCALDPC_VAR_ORDER); the decode entry points never read
+ * the environment.  key / value (text):
+ *   "path"          "auto" | "stream" (64-codeword tiles) | "edge" (row-parallel up to 64) | "lds"
+ *   "split"         stream lanes per tile group (default 2)
+ *   "group_mb"      budget of a cache-resident tile group in MB (default 215; large = stream from HBM)
+ *   "el_max"        largest call the row-parallel kernels take (default 6 min-sum / 4 tanh)
+ *   "el_fuse"       1 = two-launch early-exit loop of the row-parallel path (default), 0 = four-launch
+ *   "compact_after" iteration from which stragglers may be handed to a compact pass (default 4, 0 = never)
+ *   "minsum_loop"   1 = loop form of the min-sum check kernel (A/B)
+ *   "var_order"     order of the columns of one degree in a variable-node launch: 0 ascending column,
+ *                   1 by first edge id (default).  Results never depend on any of these. */
+int scaldpc_bp_configure(scaldpc_bp *h, const char *key, const char *value);
+/* Where a handle lives, out[4]: the device it was created on; the device (hipPointerGetAttributes)
+ * of its graph allocation, of its message workspace and of its state planes (-1 = not allocated yet).
+ * Every entry point switches to the handle's device for the call and restores the caller's. */
+int scaldpc_bp_device_of(scaldpc_bp *h, int32_t *out);
 void scaldpc_bp_destroy(scaldpc_bp *h);
 
 /* ------------------------------------------- Monte-Carlo helpers on the device (K6) */
@@ -180,6 +200,16 @@ int scaldpc_qary_create(int32_t R, int32_t N, int32_t B, const int8_t *H, int32_
 int scaldpc_qary_min_sum_batch(scaldpc_qary *h, const float *pmf, int32_t batch, uint32_t flags,
                                void *stream, int8_t *out);
 void scaldpc_qary_destroy(scaldpc_qary *h);
+/* The probability -> LLR conversion both decoders apply to their inputs, on its own:
+ * llr[r][q] = ln(max_q' pmf[r][q'] / pmf[r][q]) in f32 (+inf where pmf = 0); pmf, llr: float [rows][Q].
+ * Runs on the device with glibc's logf algorithm and the correctly rounded f32 division, so the values
+ * are bit for bit those of the host's logf (what the reference's f32::ln calls).  A row that does not
+ * sum to 1 +- 1e-3 returns SCALDPC_EPMF (the reference asserts).  flags: SCALDPC_F_DEVICE_IO. */
+int scaldpc_qary_into_llr(const float *pmf, int64_t rows, int32_t Q, uint32_t flags, void *stream, float *llr);
+/* Test / tuning knobs of one q-ary handle (defaults from SCALDPC_QARY_WAVE / SCALDPC_QARY_NO_UNROLL, read
+ * once at creation): "wave" = -1 auto | 0 codeword per lane | 1 wave per (check, codeword);
+ * "unroll" = 1 register-resident unrolled enumeration for small alphabets | 0 off. */
+int scaldpc_qary_configure(scaldpc_qary *h, const char *key, const char *value);
 
 /* DecoderSpecial: H = [H' | I_R]; first N-R variables over [-B,B], last R over [-BSUM,BSUM]. */
 int scaldpc_qary_special_create(int32_t R, int32_t N, int32_t B, int32_t BSUM, const int8_t *H,

@@ -54,6 +54,10 @@ def _declare(lib):
     lib.scaldpc_bp_last_compacted.restype = C.c_int
     lib.scaldpc_bp_last_stats.argtypes = [vp, p(C.c_int64)]
     lib.scaldpc_bp_last_stats.restype = C.c_int
+    lib.scaldpc_bp_configure.argtypes = [vp, C.c_char_p, C.c_char_p]
+    lib.scaldpc_bp_configure.restype = C.c_int
+    lib.scaldpc_bp_device_of.argtypes = [vp, p(C.c_int32)]
+    lib.scaldpc_bp_device_of.restype = C.c_int
     lib.scaldpc_bp_destroy.argtypes = [vp]
     lib.scaldpc_bp_destroy.restype = None
     lib.scaldpc_mc_fer_run.argtypes = [
@@ -71,6 +75,10 @@ def _declare(lib):
         getattr(lib, name).restype = C.c_int
     lib.scaldpc_qary_create.argtypes = [C.c_int32, C.c_int32, C.c_int32, vp, C.c_int32, p(vp)]
     lib.scaldpc_qary_min_sum_batch.argtypes = [vp, vp, C.c_int32, C.c_uint32, vp, vp]
+    lib.scaldpc_qary_configure.argtypes = [vp, C.c_char_p, C.c_char_p]
+    lib.scaldpc_qary_configure.restype = C.c_int
+    lib.scaldpc_qary_into_llr.argtypes = [vp, C.c_int64, C.c_int32, C.c_uint32, vp, vp]
+    lib.scaldpc_qary_into_llr.restype = C.c_int
     lib.scaldpc_qary_destroy.argtypes = [vp]
     lib.scaldpc_qary_destroy.restype = None
     lib.scaldpc_qary_special_create.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_int32, vp, C.c_int32, p(vp)]

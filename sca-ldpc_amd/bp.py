@@ -253,6 +253,19 @@ class BpDecoder:
     def last_row_parallel(self):
         return self.last_stats()["row_parallel"]
 
+    def configure(self, **knobs):
+        """Tuning / test knobs of this decoder (include/scaldpc.h, scaldpc_bp_configure): path, split,
+        group_mb, el_max, el_fuse, compact_after, minsum_loop, var_order.  A new decoder takes its
+        defaults from the SCALDPC_* environment once, at construction; results never depend on them."""
+        for k, v in knobs.items():
+            _lib.check(self._lib.scaldpc_bp_configure(self._h, k.encode(), str(v).encode()))
+
+    def device_of(self):
+        """{device the decoder was created on, device of its graph / message / state allocations (-1: none yet)}."""
+        out = (C.c_int32 * 4)()
+        _lib.check(self._lib.scaldpc_bp_device_of(self._h, out))
+        return {"device": out[0], "graph": out[1], "messages": out[2], "state": out[3]}
+
     def set_tile_group(self, tiles):
         _lib.check(self._lib.scaldpc_bp_set_tile_group(self._h, int(tiles)))
 

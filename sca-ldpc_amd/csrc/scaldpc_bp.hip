@@ -58,7 +58,23 @@ struct HostBuckets {
 // ===========================================================================
 // handle
 // ===========================================================================
+// Tuning / test knobs of a handle.  The environment is read ONCE, when the handle is created
+// (SCALDPC_PATH, _SPLIT, _GROUP_MB, _EL_MAX, _EL_FUSE, _COMPACT_AFTER, _MINSUM_LOOP); afterwards
+// scaldpc_bp_configure() changes them -- the decode entry points never call getenv().
+struct Knobs {
+    enum Path { AUTO = 0, STREAM = 1, EDGE = 2, LDS = 3 };
+    int path = AUTO;
+    int split = 2;            // stream lanes per tile group
+    double group_mb = 215.0;  // cache-resident group budget (auto_group)
+    int el_max = -1;          // row-parallel limit; -1 = per-method default (6 / 4)
+    int el_fuse = 1;          // early-exit row-parallel loop: fused two-launch form
+    int compact_after = -1;   // -1 = default (4); 0 = no compact pass
+    int minsum_loop = 0;      // loop form of the min-sum check kernel (A/B knob)
+    int var_order = 0;        // k_var launch order inside a degree: 0 = ascending column id, 1 = by first edge id
+};
+
 struct scaldpc_bp {
+    Knobs kn;
     int m = 0, n = 0;
     long E = 0;
     int max_row_deg = 0, max_col_deg = 0;
@@ -136,6 +152,43 @@ struct scaldpc_bp {
 
 namespace {
 
+// one knob from its textual value; false = unknown key or bad value
+bool set_knob(Knobs &k, const char *key, const char *val)
+{
+    if (!key || !val) return false;
+    if (!strcmp(key, "path")) {
+        if (!strcmp(val, "auto") || !*val) k.path = Knobs::AUTO;
+        else if (!strcmp(val, "stream")) k.path = Knobs::STREAM;
+        else if (!strcmp(val, "edge")) k.path = Knobs::EDGE;
+        else if (!strcmp(val, "lds")) k.path = Knobs::LDS;
+        else return false;
+        return true;
+    }
+    char *end = nullptr;
+    const double x = strtod(val, &end);
+    if (end == val) return false;
+    if (!strcmp(key, "split")) k.split = (int)x;
+    else if (!strcmp(key, "group_mb")) k.group_mb = x;
+    else if (!strcmp(key, "el_max")) k.el_max = (int)x;
+    else if (!strcmp(key, "el_fuse")) k.el_fuse = (int)x != 0;
+    else if (!strcmp(key, "compact_after")) k.compact_after = (int)x;
+    else if (!strcmp(key, "minsum_loop")) k.minsum_loop = (int)x != 0;
+    else if (!strcmp(key, "var_order")) k.var_order = (int)x;
+    else return false;
+    return true;
+}
+
+void knobs_from_env(Knobs &k)
+{
+    static const char *const names[][2] = {{"SCALDPC_PATH", "path"}, {"SCALDPC_SPLIT", "split"},
+                                           {"SCALDPC_GROUP_MB", "group_mb"}, {"SCALDPC_EL_MAX", "el_max"},
+                                           {"SCALDPC_EL_FUSE", "el_fuse"}, {"SCALDPC_COMPACT_AFTER", "compact_after"},
+                                           {"SCALDPC_VAR_ORDER", "var_order"}};
+    for (auto &nm : names)
+        if (const char *e = getenv(nm[0])) (void)set_knob(k, nm[1], e);
+    if (getenv("SCALDPC_MINSUM_LOOP")) k.minsum_loop = 1;  // presence switches it on, as before
+}
+
 // bucket b holds nodes with bounds[b-1] < deg <= bounds[b]; beyond the last bound -> generic (maxd 0)
 void build_buckets(const std::vector<int> &deg, const int *bounds, int nb, bool keep_isolated, HostBuckets &out)
 {
@@ -189,8 +242,7 @@ int grow(T **p, size_t *cap, size_t need)
 // 256 MiB Infinity Cache (measured knee between 209 and 261 MB, profiles/microbench)
 int auto_group(const scaldpc_bp *h, int T)
 {
-    double budget = 215e6;  // 4 tiles of the HQC-128 bench graph = 208.9 MB: fastest measured; 261 MB falls off
-    if (const char *e = getenv("SCALDPC_GROUP_MB")) budget = atof(e) * 1e6;
+    const double budget = h->kn.group_mb * 1e6;  // default 215: 4 tiles of the HQC-128 bench graph = 208.9 MB, fastest measured; 261 MB falls off
     const double per_tile = (double)h->E * TW * sizeof(float);
     const int g = per_tile > 0 ? (int)(budget / per_tile) : T;
     return std::max(1, std::min(g, T));
@@ -291,6 +343,25 @@ int ensure_tile_tables(scaldpc_bp *h)
     }
     int *meta = host + o_var_meta, *relaid = host + o_csc_list;
     int pos = 0;
+    // launch order of the columns: the bucket lists are sorted by degree, ascending column id inside a
+    // degree.  var_order = 1 re-sorts each run of equal degree by the column's FIRST edge id, so that
+    // neighbouring waves of a launch start their gathers in neighbouring rows of the message array
+    // (the records carry the column id, so the order is free; results cannot depend on it).
+    std::vector<int> order_buf;
+    const int *vlist = hv.list.data();
+    if (h->kn.var_order == 1 && !hv.list.empty()) {
+        order_buf = hv.list;
+        size_t i = 0;
+        while (i < order_buf.size()) {
+            size_t j = i;
+            while (j < order_buf.size() && cdeg[order_buf[j]] == cdeg[order_buf[i]]) j++;
+            if (cdeg[order_buf[i]] > 0)
+                std::sort(order_buf.begin() + i, order_buf.begin() + j,
+                          [&](int a, int b2) { return csc_edge[col_ptr[a]] < csc_edge[col_ptr[b2]]; });
+            i = j;
+        }
+        vlist = order_buf.data();
+    }
     for (int b = 0; b < hv.bk.nb; b++) {
         const int blocks = hv.bk.blk[b + 1] - hv.bk.blk[b];
         for (int sl = 0; sl < blocks * 4; sl++) {
@@ -300,7 +371,7 @@ int ensure_tile_tables(scaldpc_bp *h)
                 for (int k = 1; k < VAR_REC; k++) md[k] = 0;
                 continue;
             }
-            const int v = hv.list[hv.bk.off[b] + sl], d = cdeg[v];
+            const int v = vlist[hv.bk.off[b] + sl], d = cdeg[v];
             md[0] = v;
             md[1] = pos;
             md[2] = d;
@@ -399,11 +470,9 @@ int el_limit(const scaldpc_bp *h, int method)
 {
     if (h->el_waves == 0) return 0;  // empty graph, or a row / column wider than a wave
     int lim = method == SCALDPC_BP_MIN_SUM ? 6 : 4;
-    if (const char *e = getenv("SCALDPC_EL_MAX")) lim = atoi(e);
-    if (const char *f = getenv("SCALDPC_PATH")) {
-        if (!strcmp(f, "stream")) lim = 0;
-        if (!strcmp(f, "edge")) lim = TW;
-    }
+    if (h->kn.el_max >= 0) lim = h->kn.el_max;
+    if (h->kn.path == Knobs::STREAM) lim = 0;
+    if (h->kn.path == Knobs::EDGE) lim = TW;
     return std::max(0, std::min(lim, TW));
 }
 
@@ -427,7 +496,7 @@ int launch_check(scaldpc_bp *h, int method, float alpha, int G, const u64 *synd_
 #define MS_LAUNCH(W, F)                                                                                              \
     hipLaunchKernelGGL((k_check_minsum<W, F>), grid, dim3(256), 0, s, h->d_row_ptr, msg0, synd_g, done_g, skip_done, \
                        h->m, h->E, alpha, h->d_col_idx, h->d_prior)
-        const bool loop_form = getenv("SCALDPC_MINSUM_LOOP") != nullptr;  // A/B knob
+        const bool loop_form = h->kn.minsum_loop != 0;  // A/B knob
         if (h->max_row_deg <= ROW_CAP && !loop_form) {
             dim3 gridx(h->row_bk.blk[h->row_bk.nb], G);
 #define MSX_LAUNCH(CAP, F)                                                                                          \
@@ -593,8 +662,7 @@ constexpr int MAX_LANES = 4;
 // more only shrink the launches.  SCALDPC_SPLIT=n overrides (1 = single stream).
 int fixed_lanes(const scaldpc_bp *h, int g)
 {
-    int nl = 2;
-    if (const char *e = getenv("SCALDPC_SPLIT")) nl = atoi(e);
+    const int nl = h->kn.split;
     if (h->E == 0) return 1;
     return std::max(1, std::min(std::min(nl, g), MAX_LANES));
 }
@@ -711,7 +779,7 @@ int iterate_group(scaldpc_bp *h, const TileState &st, int g0, int g, int max_ite
     u64 *done_g = st.done + g0, *conv_g = st.conv + g0, *unsat_g = st.unsat + (size_t)g0 * parity_waves(h);
     int *iters_g = st.iters + (size_t)g0 * TW;
     float *post_g = st.post ? st.post + (size_t)g0 * h->n * TW : nullptr;
-    if (early && !(getenv("SCALDPC_EL_FUSE") && !strcmp(getenv("SCALDPC_EL_FUSE"), "0")))
+    if (early && h->kn.el_fuse)
         return iterate_el_early(h, el, max_iter, method, alpha, synd_g, hard_g, done_g, conv_g, unsat_g, iters_g, post_g, s);
     // row-parallel kernels, fixed iterations (or the four-launch early-exit form, SCALDPC_EL_FUSE=0)
     const bool fused = fused_init(h, method);
@@ -767,7 +835,7 @@ int decode_level(scaldpc_bp *h, int lvl, const TileState &st, int batch, int T, 
     int defer_after = 0;
     if (early && !el && lvl < scaldpc_bp::MAX_LEVELS) {
         defer_after = 4;  // measured on the config-5 sweep: 4-5 best (177k trials/s), 8: 156k, 12: 136k
-        if (const char *e = getenv("SCALDPC_COMPACT_AFTER")) defer_after = atoi(e);
+        if (h->kn.compact_after >= 0) defer_after = h->kn.compact_after;
         if (max_iter <= 2 * defer_after) defer_after = 0;  // nothing to gain
     }
     std::vector<char> deferred_tile(T, 0);
@@ -859,8 +927,7 @@ int run_core(scaldpc_bp *h, int batch, int T, int G, int max_iter, int method, f
     // small graph: the LDS-resident single-launch decoder, plane I/O (Monte-Carlo entry points)
     {
         const size_t small_lds = (size_t)2 * h->E * sizeof(float) + (size_t)2 * h->n + h->m + 64;
-        const char *force = getenv("SCALDPC_PATH");
-        if (small_lds <= 60 * 1024 && h->E > 0 && !(force && (!strcmp(force, "stream") || !strcmp(force, "edge")))) {
+        if (small_lds <= 60 * 1024 && h->E > 0 && h->kn.path != Knobs::STREAM && h->kn.path != Knobs::EDGE) {
 #define SMALL_PLANES(M)                                                                                              \
     hipLaunchKernelGGL((k_bp_small<M, true>), dim3(batch), dim3(256), small_lds, s, h->d_row_ptr, h->d_col_idx,         \
                        h->d_col_ptr, h->d_csc_edge, h->d_prior, h->m, h->n, (int)h->E, (const void *)h->d_synd,         \
@@ -927,6 +994,7 @@ int scaldpc_bp_create(int32_t m, int32_t n, int64_t nnz, const int32_t *row_ptr,
     }
     scaldpc_bp *h = new (std::nothrow) scaldpc_bp();
     if (!h) return fail(SCALDPC_ENOMEM, "out of host memory");
+    knobs_from_env(h->kn);
     h->m = m;
     h->n = n;
     h->E = nnz;
@@ -1025,6 +1093,7 @@ int scaldpc_bp_set_channel_probs(scaldpc_bp *h, const double *probs)
 {
     if (!h || !probs) return fail(SCALDPC_EINVAL, "NULL argument");
     std::lock_guard<std::mutex> lk(h->mu);
+    DeviceGuard dg(h->device);
     std::vector<float> llr(h->n);
     float last_p = 0.0f, last_llr = 0.0f;
     for (int j = 0; j < h->n; j++) {
@@ -1086,6 +1155,7 @@ int scaldpc_bp_decode_batch(scaldpc_bp *h, const uint8_t *in, int32_t input_kind
         return fail(SCALDPC_EINVAL, "unknown bp method %d", method);
     if (!(alpha >= 0.0f)) return fail(SCALDPC_EINVAL, "ms_scaling_factor must be >= 0");
     std::lock_guard<std::mutex> lk(h->mu);
+    DeviceGuard dg(h->device);
     if (!h->have_prior) return fail(SCALDPC_EINVAL, "channel probabilities not set");
     if (max_iter <= 0) max_iter = h->n;
     const bool dev_io = flags & SCALDPC_F_DEVICE_IO;
@@ -1103,11 +1173,10 @@ int scaldpc_bp_decode_batch(scaldpc_bp *h, const uint8_t *in, int32_t input_kind
 
     // Small graph: the LDS-resident single-launch decoder (k_bp_small).
     const size_t small_lds = (size_t)2 * h->E * sizeof(float) + (size_t)2 * h->n + h->m + 64;
-    const char *force = getenv("SCALDPC_PATH");  // "stream" / "edge" / "lds" pin a path (tests)
     const bool small_fits = small_lds <= 60 * 1024 && h->E > 0;
-    if (force && !strcmp(force, "lds") && !small_fits)
+    if (h->kn.path == Knobs::LDS && !small_fits)  // "stream" / "edge" / "lds" pin a path (tests)
         return fail(SCALDPC_EINVAL, "SCALDPC_PATH=lds but the graph needs %zu B of LDS", small_lds);
-    if (small_fits && !(force && (!strcmp(force, "stream") || !strcmp(force, "edge")))) {
+    if (small_fits && h->kn.path != Knobs::STREAM && h->kn.path != Knobs::EDGE) {
         const uint8_t *din = in;
         uint8_t *dbits = out_bits, *dconv = out_conv;
         float *dllr = out_llr;
@@ -1294,6 +1363,7 @@ int scaldpc_mc_fer_run(scaldpc_bp *h, int64_t first_trial, int32_t batch, uint64
 {
     SC_TRY(mc_common_args(h, batch, method, alpha, out_success));
     std::lock_guard<std::mutex> lk(h->mu);
+    DeviceGuard dg(h->device);
     CacheBypass guard(h->async_used);
     if (!h->have_prior) return fail(SCALDPC_EINVAL, "channel probabilities not set");
     if (max_iter <= 0) max_iter = h->n;
@@ -1331,6 +1401,7 @@ int scaldpc_mc_hqc_run(scaldpc_bp *h, int32_t omega, double eps, int64_t first_t
 {
     SC_TRY(mc_common_args(h, batch, method, alpha, out_success));
     std::lock_guard<std::mutex> lk(h->mu);
+    DeviceGuard dg(h->device);
     CacheBypass guard(h->async_used);
     if (!h->have_prior) return fail(SCALDPC_EINVAL, "channel probabilities not set");
     if (h->identity_from < 0) return fail(SCALDPC_EINVAL, "parity-check matrix is not of the form [Hin | I] (hqc.py:680)");
@@ -1382,11 +1453,48 @@ int scaldpc_mc_hqc_run(scaldpc_bp *h, int32_t omega, double eps, int64_t first_t
     return mc_finish(h, batch, T, N, dev_io, s, out_success, out_iters);
 }
 
+int scaldpc_bp_configure(scaldpc_bp *h, const char *key, const char *value)
+{
+    if (!h || !key || !value) return fail(SCALDPC_EINVAL, "NULL argument");
+    std::lock_guard<std::mutex> lk(h->mu);
+    DeviceGuard dg(h->device);
+    const int old_order = h->kn.var_order;
+    if (!set_knob(h->kn, key, value)) return fail(SCALDPC_EINVAL, "unknown knob or bad value: %s=%s", key, value);
+    if (h->kn.var_order != old_order && h->d_tile_tab) {  // the k_var records are laid out in launch order: rebuild on next use
+        CacheBypass guard(true);
+        SC_HIP(hipDeviceSynchronize());
+        dev_free(h->d_tile_tab);
+        h->d_var_meta = h->d_csc_list = h->d_row_list = nullptr;
+    }
+    return 0;
+}
+
+int scaldpc_bp_device_of(scaldpc_bp *h, int32_t *out)
+{
+    if (!h || !out) return fail(SCALDPC_EINVAL, "NULL argument");
+    std::lock_guard<std::mutex> lk(h->mu);
+    auto where = [](const void *p) -> int {
+        if (!p) return -1;
+        hipPointerAttribute_t at{};
+        if (hipPointerGetAttributes(&at, p) != hipSuccess) {
+            (void)hipGetLastError();
+            return -2;
+        }
+        return at.device;
+    };
+    out[0] = h->device;
+    out[1] = where(h->d_graph);
+    out[2] = where(h->d_msg ? (const void *)h->d_msg : (const void *)h->d_emsg);
+    out[3] = where(h->d_synd);
+    return 0;
+}
+
 int scaldpc_bp_time_kernels(scaldpc_bp *h, int32_t iters, int32_t method, float alpha, void *stream, float *ms,
                             int32_t *launches)
 {
     if (!h || !ms || !launches || iters <= 0) return fail(SCALDPC_EINVAL, "bad argument");
     std::lock_guard<std::mutex> lk(h->mu);
+    DeviceGuard dg(h->device);
     if (h->last_group <= 0) return fail(SCALDPC_EINVAL, "no previous decode to time");
     hipStream_t s = stream ? (hipStream_t)stream : h->own_stream;
     const int g = h->last_group;
@@ -1479,6 +1587,12 @@ int scaldpc_bp_time_kernels(scaldpc_bp *h, int32_t iters, int32_t method, float 
 void scaldpc_bp_destroy(scaldpc_bp *h)
 {
     if (!h) return;
+    DeviceGuard dg(h->device);
+    // A handle that took SCALDPC_F_ASYNC calls may still have work in flight, on the caller's stream and
+    // on its own lanes: wait for the device, and send its blocks through hipFree instead of parking
+    // them for the next handle.  The guard must be in place BEFORE the first block is released.
+    CacheBypass guard(h->async_used);
+    if (h->async_used) (void)hipDeviceSynchronize();
     dev_free(h->d_graph);  // graph arrays and d_prior are views into it
     dev_free(h->d_tile_tab);
     dev_free(h->d_el_tab);
@@ -1493,7 +1607,6 @@ void scaldpc_bp_destroy(scaldpc_bp *h)
     }
     dev_free(h->d_emsg); dev_free(h->d_el_unsat);
     dev_free(h->d_thr); dev_free(h->d_mc); dev_free(h->d_diff); dev_free(h->d_ylist); dev_free(h->d_succ);
-    CacheBypass guard(h->async_used);
     cached_free(h->h_remaining);
     if (h->own_stream) stream_release(h->own_stream, h->device);
     for (int k = 0; k < 4; k++) {

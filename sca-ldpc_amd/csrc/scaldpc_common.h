@@ -44,6 +44,24 @@ struct CacheBypass {
     bool prev;
 };
 
+// Every entry point that takes a handle runs on the handle's device whatever the calling thread's
+// current device is (allocations, streams and launches all follow the current device), and puts
+// the caller's device back on return.
+struct DeviceGuard {
+    int prev = -1;
+    bool switched = false;
+    explicit DeviceGuard(int device)
+    {
+        if (hipGetDevice(&prev) == hipSuccess && prev != device) switched = hipSetDevice(device) == hipSuccess;
+    }
+    ~DeviceGuard()
+    {
+        if (switched) (void)hipSetDevice(prev);
+    }
+    DeviceGuard(const DeviceGuard &) = delete;
+    DeviceGuard &operator=(const DeviceGuard &) = delete;
+};
+
 // Streams of destroyed handles are parked per device and handed to the next handle created there.
 int stream_acquire(hipStream_t *out, int *device);
 void stream_release(hipStream_t s, int device);

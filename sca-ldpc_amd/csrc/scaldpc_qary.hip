@@ -23,15 +23,11 @@
 // This path is ALU/LDS bound (Q^(DC-1) assignments per check), not HBM bound; no
 // roofline claim is made for it.
 #include "scaldpc_common.h"
-
-#include <chrono>
+#include "scaldpc_logf.h"
 
 #include <cmath>
-#include <condition_variable>
-#include <functional>
 #include <cstring>
 #include <mutex>
-#include <thread>
 #include <utility>
 #include <vector>
 
@@ -46,10 +42,14 @@ constexpr int QERR_PMF = 3;        // decoder.rs:683-684 assert
 
 __device__ __forceinline__ bool finite_f(float x) { return fabsf(x) < INFINITY; }  // false for inf and NaN
 
-// decoder.rs:668-692 on the device (DEVICE_IO path; the host path converts with glibc so
-// that LLRs are bit-identical to the oracle's).  pmf: [batch][nv][Q] -> llr [nv][Q][Bp].
+// decoder.rs:668-692 on the device: llr[q] = ln(max_p / p[q]) in f32, with glibc's logf restated
+// for the device (scaldpc_logf.h) and the correctly rounded f32 division, so the LLRs are bit for bit
+// what the reference's f32::ln gives on the host -- for host and device inputs alike.
+// pmf: [batch][nv][Q] -> llr [nv][Q][Bp].  thread = (variable, codeword).
+// A row that does not sum to 1 +- 1e-3 (or has no maximum: all NaN) is the reference's assert
+// (decoder.rs:683-684): the smallest offending (codeword, variable) is left in *first_bad.
 __global__ void k_q_into_llr(const float *__restrict__ pmf, int nv, int Q, int batch, long Bp,
-                             float *__restrict__ llr, int *__restrict__ err)
+                             float *__restrict__ llr, int *__restrict__ err, u64 *__restrict__ first_bad, int kind)
 {
     const long b = (long)blockIdx.y * blockDim.x + threadIdx.x;
     const int v = blockIdx.x;
@@ -68,8 +68,35 @@ __global__ void k_q_into_llr(const float *__restrict__ pmf, int nv, int Q, int b
             have = true;
         }
     }
-    if (!have || !(sum < 1.0f + 0.001f) || !(sum > 1.0f - 0.001f)) atomicMax(err, QERR_PMF);
-    for (int q = 0; q < Q; q++) llr[((size_t)v * Q + q) * Bp + b] = logf(mx / p[q]);
+    if (!have || !(sum < 1.0f + 0.001f) || !(sum > 1.0f - 0.001f)) {
+        atomicMax(err, QERR_PMF);
+        // key: codeword, then alphabet (0 = coefficient rows, 1 = row-sum rows), then variable, then "no maximum"
+        atomicMin(first_bad, ((u64)b << 32) | ((u64)kind << 31) | ((u64)v << 1) | (have ? 0ull : 1ull));
+    }
+    // measured channel outputs repeat a handful of rows: no point caching across lanes, the double
+    // pipe is idle anyway (18 double operations per symbol)
+    for (int q = 0; q < Q; q++) llr[((size_t)v * Q + q) * Bp + b] = glibc_logf(mx / p[q]);
+}
+
+// The same conversion on rows as they stand: pmf [rows][Q] -> llr [rows][Q] (scaldpc_qary_into_llr).
+// bad[0] = smallest row index that fails the sum test (or has no maximum), as k_q_into_llr's key.
+__global__ void k_q_into_llr_rows(const float *__restrict__ pmf, long rows, int Q, float *__restrict__ llr,
+                                  u64 *__restrict__ first_bad)
+{
+    const long r = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= rows) return;
+    const float *p = pmf + (size_t)r * Q;
+    float sum = 0.0f, mx = 0.0f;
+    bool have = false;
+    for (int q = 0; q < Q; q++) {
+        sum += p[q];
+        if (p[q] == p[q] && (!have || p[q] > mx)) {
+            mx = p[q];
+            have = true;
+        }
+    }
+    if (!have || !(sum < 1.0f + 0.001f) || !(sum > 1.0f - 0.001f)) atomicMin(first_bad, ((u64)r << 1) | (have ? 0ull : 1ull));
+    for (int q = 0; q < Q; q++) llr[(size_t)r * Q + q] = glibc_logf(mx / p[q]);
 }
 
 // decoder.rs:567-573: v2c = channel * h.  thread = (edge, codeword).
@@ -586,9 +613,11 @@ struct scaldpc_qary {
     signed char *d_hard = nullptr, *d_out = nullptr;
     size_t cap_pmf = 0, cap_pmf2 = 0, cap_out = 0;
     int *d_err = nullptr;
-    float *h_llr = nullptr;  // pinned staging of the host-side probability -> LLR conversion
-    size_t cap_h_llr = 0;
+    u64 *d_first_bad = nullptr;  // smallest (codeword, variable) key whose pmf row fails the sum test
     hipStream_t own_stream = nullptr;
+    int device = 0;      // the device the handle was created on; every entry point runs there
+    int kn_wave = -1;    // -1: wave-parallel enumeration for batches <= 256 and the special decoder; 0 / 1 force
+    int kn_unroll = 1;   // register-resident unrolled enumeration for small alphabets
     std::mutex mu;
 };
 
@@ -679,6 +708,10 @@ int qary_build(int R, int N, int B, int BSUM, bool special, const int8_t *H, int
     if (!rc && hipMemcpy(h->d_var_off, h->h_var_off.data(), sizeof(long) * N, hipMemcpyHostToDevice) != hipSuccess)
         rc = fail(SCALDPC_EHIP, "hipMemcpy failed");
     if (!rc) rc = dev_alloc(&h->d_err, 1);
+    if (!rc) rc = dev_alloc(&h->d_first_bad, 1);
+    if (!rc && hipGetDevice(&h->device) != hipSuccess) rc = fail(SCALDPC_EHIP, "hipGetDevice failed");
+    if (const char *e = getenv("SCALDPC_QARY_WAVE")) h->kn_wave = atoi(e) != 0;  // the environment is read once per handle
+    if (getenv("SCALDPC_QARY_NO_UNROLL")) h->kn_unroll = 0;
     if (!rc && hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking) != hipSuccess)
         rc = fail(SCALDPC_EHIP, "hipStreamCreate failed");
     if (rc) {
@@ -700,145 +733,13 @@ int growq(T **p, size_t *cap, size_t need)
     return 0;
 }
 
-// decoder.rs:668-692 on the host with glibc logf -- bit-identical to the oracle (and to what
-// the reference's f32::ln gives on the same platform).  One logf per symbol is the dominant
-// host cost of a large batch, so codewords are split over host threads.
-// A few persistent host threads for the probability -> LLR conversion (spawning sixteen threads per
-// call cost a third of the conversion at config-4 size).  One job at a time (callers serialise on
-// the pool's mutex); workers are detached and live as long as the process.
-class HostPool {
-  public:
-    static HostPool &get()
-    {
-        static HostPool *p = new HostPool();
-        return *p;
-    }
-    // runs fn(0) ... fn(n - 1), fn(0) on the calling thread
-    void run(int n, const std::function<void(int)> &fn)
-    {
-        if (n <= 1) {
-            fn(0);
-            return;
-        }
-        std::lock_guard<std::mutex> job(job_mu_);
-        {
-            std::unique_lock<std::mutex> lk(mu_);
-            while ((int)workers_ < n - 1) {
-                const int id = workers_++;
-                std::thread([this, id] { loop(id); }).detach();
-            }
-            fn_ = &fn;
-            n_ = n;
-            pending_ = n - 1;
-            epoch_++;
-        }
-        cv_.notify_all();
-        fn(0);
-        std::unique_lock<std::mutex> lk(mu_);
-        done_.wait(lk, [this] { return pending_ == 0; });
-        fn_ = nullptr;
-    }
-
-  private:
-    void loop(int id)
-    {
-        unsigned long seen = 0;
-        for (;;) {
-            const std::function<void(int)> *fn;
-            {
-                std::unique_lock<std::mutex> lk(mu_);
-                cv_.wait(lk, [&] { return epoch_ != seen; });
-                seen = epoch_;
-                if (id + 1 >= n_) continue;  // this job needs fewer workers
-                fn = fn_;
-            }
-            (*fn)(id + 1);
-            std::unique_lock<std::mutex> lk(mu_);
-            if (--pending_ == 0) done_.notify_one();
-        }
-    }
-    std::mutex job_mu_, mu_;
-    std::condition_variable cv_, done_;
-    const std::function<void(int)> *fn_ = nullptr;
-    int n_ = 0, pending_ = 0;
-    unsigned workers_ = 0;
-    unsigned long epoch_ = 0;
-};
-
-int host_into_llr(const float *pmf, int batch, int nv, int Q, long Bp, long row0, float *llr)
-{
-    const size_t work = (size_t)batch * nv * Q;
-    int nthreads = 1;
-    if (work > 200000) nthreads = (int)std::min<size_t>(std::max(1u, std::thread::hardware_concurrency()), 16);
-    nthreads = std::max(1, std::min(nthreads, (batch + 63) / 64));
-    std::vector<int> bad_b(nthreads, -1), bad_v(nthreads, -1), bad_kind(nthreads, 0);
-    std::vector<float> bad_sum(nthreads, 0.0f);
-    // a thread owns 64-codeword chunks: the [batch][var][q] -> [var][q][Bp] transposition then
-    // WRITES 64 contiguous floats per (var, q) instead of one float per 4 KB stride
-    const int nchunks = (batch + 63) / 64;
-    auto worker = [&](int tid) {
-        float mx[64];
-        for (int ch = tid; ch < nchunks; ch += nthreads) {
-            const int b0 = ch * 64, nb = std::min(64, batch - b0);
-            for (int v = 0; v < nv; v++) {
-                for (int i = 0; i < nb; i++) {
-                    const int b = b0 + i;
-                    const float *p = pmf + ((size_t)b * nv + v) * Q;
-                    float sum = 0.0f, m_ = 0.0f;
-                    bool have = false;
-                    for (int q = 0; q < Q; q++) {
-                        sum += p[q];
-                        if (p[q] == p[q] && (!have || p[q] > m_)) {
-                            m_ = p[q];
-                            have = true;
-                        }
-                    }
-                    mx[i] = m_;
-                    if ((!have || !(sum < 1.0f + 0.001f) || !(sum > 1.0f - 0.001f)) &&
-                        (bad_b[tid] < 0 || b < bad_b[tid] || (b == bad_b[tid] && v < bad_v[tid]))) {
-                        bad_b[tid] = b; bad_v[tid] = v; bad_kind[tid] = have ? 2 : 1; bad_sum[tid] = sum;
-                    }
-                }
-                for (int q = 0; q < Q; q++) {
-                    float *dst = llr + ((size_t)(row0 + (long)v * Q + q)) * Bp + b0;
-                    // measured channel outputs repeat a handful of pmf rows (decode.py:232-237 has two):
-                    // remember the last (max, p) -> ln(max / p) and skip the division and the logf when the
-                    // next codeword brings the same pair (same function, same result)
-                    float lm = -1.0f, lp = -1.0f, lv = 0.0f;
-                    for (int i = 0; i < nb; i++) {
-                        const float pv = pmf[((size_t)(b0 + i) * nv + v) * Q + q];
-                        if (!(pv == lp && mx[i] == lm)) {
-                            lm = mx[i];
-                            lp = pv;
-                            lv = logf(lm / lp);
-                        }
-                        dst[i] = lv;
-                    }
-                    for (int i = nb; i < 64; i++) dst[i] = 0.0f;  // padding lanes: all-equal messages
-                }
-            }
-        }
-    };
-    HostPool::get().run(nthreads, worker);
-    int first = -1;
-    for (int t = 0; t < nthreads; t++)
-        if (bad_b[t] >= 0 && (first < 0 || bad_b[t] < bad_b[first] || (bad_b[t] == bad_b[first] && bad_v[t] < bad_v[first])))
-            first = t;
-    if (first >= 0) {
-        if (bad_kind[first] == 1)
-            return fail(SCALDPC_EPMF, "No maximum probability found (codeword %d, variable %d)", bad_b[first], bad_v[first]);
-        return fail(SCALDPC_EPMF, "channel output of codeword %d, variable %d sums to %g, not 1 +- 1e-3", bad_b[first],
-                    bad_v[first], (double)bad_sum[first]);
-    }
-    return 0;
-}
-
 int qary_run(scaldpc_qary *h, const float *pmf_b, const float *pmf_s, int batch, uint32_t flags, void *stream,
              int8_t *out)
 {
     if (!h || !pmf_b || !out || (h->special && !pmf_s)) return fail(SCALDPC_EINVAL, "NULL argument");
     if (batch <= 0) return fail(SCALDPC_EINVAL, "batch must be positive");
     std::lock_guard<std::mutex> lk(h->mu);
+    DeviceGuard dg(h->device);
     const bool dev_io = flags & SCALDPC_F_DEVICE_IO;
     hipStream_t s = stream ? (hipStream_t)stream : h->own_stream;
     const long Bp = ((long)batch + 63) / 64 * 64;
@@ -852,34 +753,28 @@ int qary_run(scaldpc_qary *h, const float *pmf_b, const float *pmf_s, int batch,
         h->cap_bp = Bp;
     }
     SC_HIP(hipMemsetAsync(h->d_err, 0, sizeof(int), s));
+    SC_HIP(hipMemsetAsync(h->d_first_bad, 0xFF, sizeof(u64), s));
     const int TB = 64;
+    // probabilities -> LLRs on the device (host inputs are staged as they are: [batch][var][Q] floats)
+    const float *dp_b = pmf_b, *dp_s = pmf_s;
     if (!dev_io) {
-        // pinned staging buffer kept by the handle: a fresh 5 MB vector per call cost more in page
-        // faults and the pageable copy than the conversion itself
-        const size_t need = (size_t)h->llr_rows * Bp;
-        if (need > h->cap_h_llr) {
-            cached_free(h->h_llr);
-            h->h_llr = nullptr;
-            h->cap_h_llr = 0;
-            SC_TRY(cached_alloc((void **)&h->h_llr, need * sizeof(float), true));
-            h->cap_h_llr = need;
-        }
-        const auto t0__ = std::chrono::steady_clock::now();
-        SC_TRY(host_into_llr(pmf_b, batch, BV, h->Q, Bp, 0, h->h_llr));
-        if (getenv("SCALDPC_TIMING"))
-            fprintf(stderr, "[qary] into_llr %.1f us\n",
-                    std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0__).count());
-        if (h->special) SC_TRY(host_into_llr(pmf_s, batch, h->R, h->QS, Bp, (long)BV * h->Q, h->h_llr));
-        SC_HIP(hipMemcpyAsync(h->d_llr, h->h_llr, need * sizeof(float), hipMemcpyHostToDevice, s));
-    } else {
-        hipLaunchKernelGGL(k_q_into_llr, dim3(BV, Bp / TB), dim3(TB), 0, s, pmf_b, BV, h->Q, batch, Bp, h->d_llr,
-                           h->d_err);
-        SC_HIP(hipGetLastError());
+        const size_t nb = (size_t)batch * BV * h->Q, ns = h->special ? (size_t)batch * h->R * h->QS : 0;
+        SC_TRY(growq(&h->d_pmf, &h->cap_pmf, nb));
+        SC_HIP(hipMemcpyAsync(h->d_pmf, pmf_b, nb * sizeof(float), hipMemcpyHostToDevice, s));
+        dp_b = h->d_pmf;
         if (h->special) {
-            hipLaunchKernelGGL(k_q_into_llr, dim3(h->R, Bp / TB), dim3(TB), 0, s, pmf_s, h->R, h->QS, batch, Bp,
-                               h->d_llr + (size_t)BV * h->Q * Bp, h->d_err);
-            SC_HIP(hipGetLastError());
+            SC_TRY(growq(&h->d_pmf2, &h->cap_pmf2, ns));
+            SC_HIP(hipMemcpyAsync(h->d_pmf2, pmf_s, ns * sizeof(float), hipMemcpyHostToDevice, s));
+            dp_s = h->d_pmf2;
         }
+    }
+    hipLaunchKernelGGL(k_q_into_llr, dim3(BV, Bp / TB), dim3(TB), 0, s, dp_b, BV, h->Q, batch, Bp, h->d_llr, h->d_err,
+                       h->d_first_bad, 0);
+    SC_HIP(hipGetLastError());
+    if (h->special) {
+        hipLaunchKernelGGL(k_q_into_llr, dim3(h->R, Bp / TB), dim3(TB), 0, s, dp_s, h->R, h->QS, batch, Bp,
+                           h->d_llr + (size_t)BV * h->Q * Bp, h->d_err, h->d_first_bad, 1);
+        SC_HIP(hipGetLastError());
     }
     if (h->E) {
         hipLaunchKernelGGL(k_q_init, dim3(h->E, Bp / TB), dim3(TB), 0, s, h->d_edge_var, h->d_edge_h, h->d_var_q,
@@ -903,10 +798,10 @@ int qary_run(scaldpc_qary *h, const float *pmf_b, const float *pmf_s, int batch,
     // the special decoder (15625 assignments per check at the Kyber shape) prefers wave mode at
     // every batch size measured (93 vs 153 ms at batch 256)
     bool wave_mode = (batch <= 256 || h->special) && wave_lds <= 64 * 1024;
-    if (const char *e = getenv("SCALDPC_QARY_WAVE")) wave_mode = atoi(e) != 0 && wave_lds <= 64 * 1024;
+    if (h->kn_wave >= 0) wave_mode = h->kn_wave != 0 && wave_lds <= 64 * 1024;
     // small alphabets: fully unrolled register enumeration (any batch size)
     int unrolled = 0;
-    if (!h->special && !getenv("SCALDPC_QARY_NO_UNROLL")) {
+    if (!h->special && h->kn_unroll) {
         if (h->Q == 3 && h->maxdc <= 7) unrolled = 3;
         if (h->Q == 5 && h->maxdc <= 5) unrolled = 5;
     }
@@ -945,10 +840,17 @@ int qary_run(scaldpc_qary *h, const float *pmf_b, const float *pmf_s, int batch,
     hipLaunchKernelGGL(k_q_unpack, dim3((h->N + 255) / 256, batch), dim3(256), 0, s, h->d_hard, h->N, batch, Bp, dout);
     SC_HIP(hipGetLastError());
     int err = 0;
+    u64 bad = ~0ull;
     SC_HIP(hipMemcpyAsync(&err, h->d_err, sizeof(int), hipMemcpyDeviceToHost, s));
+    SC_HIP(hipMemcpyAsync(&bad, h->d_first_bad, sizeof(u64), hipMemcpyDeviceToHost, s));
     if (!dev_io) SC_HIP(hipMemcpyAsync(out, dout, (size_t)batch * h->N, hipMemcpyDeviceToHost, s));
     SC_HIP(hipStreamSynchronize(s));
-    if (err == QERR_PMF) return fail(SCALDPC_EPMF, "a channel-output row does not sum to 1 +- 1e-3 (decoder.rs:683-684)");
+    if (err == QERR_PMF) {
+        const int bb = (int)(bad >> 32), vv = (int)((bad & 0x7fffffffull) >> 1) + (((bad >> 31) & 1) ? BV : 0);
+        if (bad & 1) return fail(SCALDPC_EPMF, "No maximum probability found (codeword %d, variable %d)", bb, vv);
+        return fail(SCALDPC_EPMF, "channel output of codeword %d, variable %d does not sum to 1 +- 1e-3 (decoder.rs:683-684)",
+                    bb, vv);
+    }
     if (err == QERR_NO_CONFIG)
         return fail(SCALDPC_ENOCONF, "a check node admits no finite configuration (decoder.rs:618)");
     if (err == QERR_NO_FINITE)
@@ -971,6 +873,64 @@ int scaldpc_qary_special_create(int32_t R, int32_t N, int32_t B, int32_t BSUM, c
     return qary_build(R, N, B, BSUM, true, H, iterations, out);
 }
 
+int scaldpc_qary_into_llr(const float *pmf, int64_t rows, int32_t Q, uint32_t flags, void *stream, float *llr)
+{
+    if (!pmf || !llr) return fail(SCALDPC_EINVAL, "NULL argument");
+    if (rows <= 0 || Q <= 0) return fail(SCALDPC_EINVAL, "rows and Q must be positive");
+    const bool dev_io = flags & SCALDPC_F_DEVICE_IO;
+    hipStream_t s = (hipStream_t)stream;  // NULL: the default stream (this call owns no handle)
+    const size_t cnt = (size_t)rows * Q;
+    float *d_p = nullptr, *d_l = nullptr;
+    u64 *d_bad = nullptr;
+    auto cleanup = [&]() {
+        dev_free(d_bad);
+        if (!dev_io) {
+            dev_free(d_p);
+            dev_free(d_l);
+        }
+    };
+    int rc = dev_alloc(&d_bad, 1);
+    if (!rc && !dev_io) {
+        rc = dev_alloc(&d_p, cnt);
+        if (!rc) rc = dev_alloc(&d_l, cnt);
+    }
+    if (rc) {
+        cleanup();
+        return rc;
+    }
+    u64 bad = ~0ull;
+    hipError_t e = hipMemsetAsync(d_bad, 0xFF, sizeof(u64), s);
+    if (e == hipSuccess && !dev_io) e = hipMemcpyAsync(d_p, pmf, cnt * sizeof(float), hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_q_into_llr_rows, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, s, dev_io ? pmf : d_p, (long)rows, Q,
+                           dev_io ? llr : d_l, d_bad);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess && !dev_io) e = hipMemcpyAsync(llr, d_l, cnt * sizeof(float), hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(&bad, d_bad, sizeof(u64), hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    cleanup();
+    if (e != hipSuccess) return fail(SCALDPC_EHIP, "into_llr failed: %s", hipGetErrorString(e));
+    if (bad != ~0ull) {
+        if (bad & 1) return fail(SCALDPC_EPMF, "No maximum probability found (row %lld)", (long long)(bad >> 1));
+        return fail(SCALDPC_EPMF, "channel output row %lld does not sum to 1 +- 1e-3 (decoder.rs:683-684)", (long long)(bad >> 1));
+    }
+    return 0;
+}
+
+int scaldpc_qary_configure(scaldpc_qary *h, const char *key, const char *value)
+{
+    if (!h || !key || !value) return fail(SCALDPC_EINVAL, "NULL argument");
+    std::lock_guard<std::mutex> lk(h->mu);
+    if (!strcmp(key, "wave"))
+        h->kn_wave = atoi(value) < 0 ? -1 : atoi(value) != 0;
+    else if (!strcmp(key, "unroll"))
+        h->kn_unroll = atoi(value) != 0;
+    else
+        return fail(SCALDPC_EINVAL, "unknown knob %s", key);
+    return 0;
+}
+
 int scaldpc_qary_min_sum_batch(scaldpc_qary *h, const float *pmf, int32_t batch, uint32_t flags, void *stream,
                                int8_t *out)
 {
@@ -988,10 +948,11 @@ int scaldpc_qary_special_min_sum_batch(scaldpc_qary *h, const float *pmf_b, cons
 void scaldpc_qary_destroy(scaldpc_qary *h)
 {
     if (!h) return;
+    DeviceGuard dg(h->device);
+    dev_free(h->d_first_bad);
     dev_free(h->d_row_ptr); dev_free(h->d_col_ptr); dev_free(h->d_csc_edge); dev_free(h->d_edge_var);
     dev_free(h->d_edge_h); dev_free(h->d_var_q); dev_free(h->d_var_off); dev_free(h->d_msg); dev_free(h->d_llr);
     dev_free(h->d_pmf); dev_free(h->d_pmf2); dev_free(h->d_hard); dev_free(h->d_out); dev_free(h->d_err);
-    cached_free(h->h_llr);
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
     delete h;
 }

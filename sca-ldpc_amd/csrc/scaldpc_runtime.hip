@@ -173,7 +173,8 @@ void stream_release(hipStream_t s, int dev)
 {
     StreamPool &sp = stream_pool();
     std::lock_guard<std::mutex> lk(sp.mu);
-    // the handle synchronised its stream before every return, nothing is in flight
+    // nothing is in flight: a handle synchronises its streams before every return, and one that took
+    // SCALDPC_F_ASYNC calls synchronises the device in its destroy before it gets here
     if (sp.idle.size() < 64) sp.idle.emplace_back(dev, s); else (void)hipStreamDestroy(s);
 }
 

@@ -47,6 +47,11 @@ class _QaryBase:
             raise ValueError("Reached the end of the array, no more space left! (node degree exceeds DV/DC)")
         return np.ascontiguousarray(H)
 
+    def configure(self, **knobs):
+        """wave = -1 (auto) / 0 / 1, unroll = 0 / 1 (include/scaldpc.h, scaldpc_qary_configure)."""
+        for k, v in knobs.items():
+            _lib.check(self._lib.scaldpc_qary_configure(self._h, k.encode(), str(v).encode()))
+
     def close(self):
         if getattr(self, "_h", None):
             self._lib.scaldpc_qary_destroy(self._h)
@@ -119,6 +124,19 @@ class QarySpecialDecoder(_QaryBase):
         if p.ndim != 2 or ps.ndim != 2:
             raise ValueError("channel outputs must be 2-D")
         return [int(x) for x in self.min_sum_batch(p[None], ps[None])[0]]
+
+
+def into_llr(channel_output):
+    """Decoder::into_llr (decoder.rs:668-692) on the device: float32 [rows, Q] probabilities ->
+    float32 [rows, Q] LLRs ln(max / p), bit-identical to the host's logf; raises if a row does not
+    sum to 1 +- 1e-3."""
+    p = np.ascontiguousarray(channel_output, dtype=np.float32)
+    if p.ndim != 2:
+        raise ValueError("channel output must be 2-D [rows, Q]")
+    out = np.empty_like(p)
+    lib = _lib.load()
+    _lib.check(lib.scaldpc_qary_into_llr(_lib.ptr(p), p.shape[0], p.shape[1], 0, None, _lib.ptr(out)))
+    return out
 
 
 _cache = {}

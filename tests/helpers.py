@@ -110,9 +110,32 @@ def compare_with_reference_form(got, ref64, tol=1e-3, clamp=30.0):
     """HIP fp32 tanh rule vs the float64 probability-ratio recursion the reference's
     package runs ("product_sum", oracle method 0).  Stated fp32 tolerance (SURVEY.md
     App. A): after clamping |L| <= 30, |dL| <= 1e-3 * max(1, |L|); hard decisions
-    exact wherever the reference's |L| exceeds that tolerance."""
+    exact wherever the reference's |L| exceeds that tolerance.  (inf - inf = NaN posteriors, which
+    +-inf priors can produce on both sides, must sit in the same places.)"""
     a = np.clip(got["llr"].astype(np.float64), -clamp, clamp)
     b = np.clip(ref64["llr"], -clamp, clamp)
-    assert (np.abs(a - b) <= tol * np.maximum(1.0, np.abs(b))).all()
-    decided = np.abs(ref64["llr"]) > tol
+    nan = np.isnan(b)
+    assert np.array_equal(np.isnan(a), nan), "NaN posteriors in different places"
+    assert (np.abs(a - b)[~nan] <= (tol * np.maximum(1.0, np.abs(b)))[~nan]).all()
+    with np.errstate(invalid="ignore"):
+        decided = ~nan & (np.abs(ref64["llr"]) > tol)
     assert np.array_equal(got["bits"][decided], ref64["bits"][decided])
+
+
+def check_reference_form(oracle, got, H, probs, x, kind, max_iter, early, min_fraction=0.0, threads=8):
+    """The independent check of every product-sum parity test: the HIP result against the float64
+    probability-ratio recursion of the reference's package (oracle method 0) -- a different
+    formulation in a different precision, so nothing here can mirror the device.  Compared on the
+    codewords whose float64 decode settles (converged, and the same iteration count as the device):
+    a trial that never converges wanders chaotically and float32 and float64 part ways on it by
+    construction.  `min_fraction` keeps the check from going vacuous.  Returns the fraction compared."""
+    with np.errstate(divide="ignore", invalid="ignore"):
+        ref64 = oracle.bp_decode_batch(H, probs, x, kind, max_iter, "product_sum", dtype="f64", threads=threads,
+                                       early_exit=early)
+    keep = ref64["converged"].astype(bool) & (got["iters"] == ref64["iters"])
+    frac = float(keep.mean())
+    assert frac >= min_fraction, f"only {frac:.2f} of the codewords qualify for the float64 comparison"
+    if keep.any():
+        compare_with_reference_form({k: (v[keep] if v is not None else None) for k, v in got.items()},
+                                    {k: (v[keep] if v is not None else None) for k, v in ref64.items()})
+    return frac

@@ -67,7 +67,7 @@ def test_config5_sweep_sheds_stragglers_twice(monkeypatch):
     a = dec.mc_hqc_run(8192, omega=omega, eps=0.05, seed=7)
     st = dec.last_stats()
     assert st["compacted"] > 0 and st["levels"] >= 2, st
-    monkeypatch.setenv("SCALDPC_COMPACT_AFTER", "0")
+    dec.configure(compact_after=0)
     b = dec.mc_hqc_run(8192, omega=omega, eps=0.05, seed=7)
     assert dec.last_stats()["levels"] == 0
     dec.close()

@@ -188,7 +188,7 @@ def test_wave_parallel_mode_equals_lane_mode(oracle, golden, monkeypatch):
     dec = qary.decoder_class("DecoderN450R150V3C7B1")(g.to_dense(np.int8), 5)
     out = {}
     for mode in ("1", "0"):
-        monkeypatch.setenv("SCALDPC_QARY_WAVE", mode)
+        dec.configure(wave=mode)
         out[mode] = dec.min_sum_batch(pmf)
     assert np.array_equal(out["0"], out["1"])
     assert np.array_equal(out["1"], oracle.qary_min_sum_batch(g, 3, pmf, 5, threads=4))
@@ -199,10 +199,47 @@ def test_wave_parallel_mode_equals_lane_mode(oracle, golden, monkeypatch):
     dk = qary.decoder_class("DecoderN1280R512SW6")(gk.to_dense(np.int8), 2)
     t = {}
     for mode in ("1", "0"):
-        monkeypatch.setenv("SCALDPC_QARY_WAVE", mode)
+        dk.configure(wave=mode)
         dk.min_sum_batch(pb, ps)
         t0 = time.perf_counter()
         out[mode] = dk.min_sum_batch(pb, ps)
         t[mode] = time.perf_counter() - t0
     assert np.array_equal(out["0"], out["1"])
     print(f"Kyber N1280R512SW6, batch 2, 2 iterations: wave mode {t['1']*1e3:.2f} ms, lane mode {t['0']*1e3:.2f} ms")
+
+
+def test_into_llr_known_answer_on_the_device():
+    """decoder.rs:744-768 through the device conversion: exact f32 values 0, 1.945_910_1, +inf."""
+    p = np.array([[0, 0, 0, 0, .14, .14, .14, .14, .14, .14, .14, .02, 0, 0, 0]] * 6, dtype=np.float32)
+    llr = qary.into_llr(p)
+    inf = np.float32(np.inf)
+    exp = np.array([inf] * 4 + [0] * 7 + [np.float32(1.945_910_1)] + [inf] * 3, dtype=np.float32)
+    assert all(np.array_equal(row, exp) for row in llr)
+    with pytest.raises(Exception, match="sum"):
+        qary.into_llr(np.full((2, 3), 0.5, dtype=np.float32))
+
+
+def test_into_llr_on_the_device_is_bit_identical_to_the_hosts_logf(oracle):
+    """The probability -> LLR conversion runs on the device with glibc's logf algorithm
+    (csrc/scaldpc_logf.h) and the correctly rounded f32 division.  2^24 rows (p, 1 - p) with p drawn
+    over all magnitudes -- uniform mantissas, exponents from the subnormals up to 1/2, so the ratio
+    max / p sweeps [1, 2^149] -- plus the edge cases, against the CPU oracle's host conversion (libm
+    logf, what the reference's f32::ln calls): every LLR bit for bit."""
+    rng = np.random.RandomState(2024)
+    n = 1 << 24
+    expo = rng.randint(0, 127, size=n).astype(np.uint32)          # biased exponent 0 (subnormal) .. 126 (< 1)
+    mant = rng.randint(0, 1 << 23, size=n).astype(np.uint32)
+    small = ((expo << 23) | mant).view(np.float32)
+    small = np.minimum(small, np.float32(0.5))
+    big = (np.float32(1.0) - small).astype(np.float32)
+    pmf = np.stack([big, small], axis=1)
+    edge = np.array([[1.0, 0.0], [0.5, 0.5], [0.5, 0.50048828125], [1.0, 1e-45], [0.9995, 1.1754944e-38],
+                     [0.75, 0.25], [0.3333333, 0.6666667], [1.0005, 0.0], [0.9995, 0.0]], dtype=np.float32)
+    pmf = np.concatenate([edge, pmf]).astype(np.float32)
+    got = qary.into_llr(pmf)
+    ref = oracle.qary_into_llr(pmf)
+    assert got.dtype == np.float32 and np.array_equal(got.view(np.uint32), ref.view(np.uint32))
+    assert np.isinf(got[0, 1]) and got[1, 0] == 0.0
+    # three-symbol rows as the decoders see them (decode.py:232-237 and random pmfs)
+    q3 = rng.dirichlet(np.ones(3), size=1 << 18).astype(np.float32)
+    assert np.array_equal(qary.into_llr(q3).view(np.uint32), oracle.qary_into_llr(q3).view(np.uint32))
