@@ -12,6 +12,8 @@
  *   scaldpc_bp_create            ldpc.bp_decoder.__init__ dense->sparse graph build,
  *                                call sites simulate/decode.py:155-161, simulate/hqc.py:694-699
  *   scaldpc_bp_set_channel_probs the `error_rate=` / `channel_probs=` constructor kwargs (same sites)
+ *   scaldpc_bp_append_rows /     the attack loop's growing H: add_check's np.vstack (simulate/hqc.py:885-908) and the
+ *     _set_channel_probs_tail    decoder rebuild of every decode (hqc.py:680,694) -> rows appended to a live decoder
  *   scaldpc_bp_decode_batch      ldpc.bp_decoder.decode(v), simulate/decode.py:171, simulate/hqc.py:708
  *                                (batched: one call = `batch` independent decode() calls)
  *   scaldpc_bp_destroy           object lifetime
@@ -96,6 +98,25 @@ int scaldpc_bp_create(int32_t m, int32_t n, int64_t nnz, const int32_t *row_ptr,
 /* Per-bit prior error probabilities, float64 [n] (host). p = 0 / p = 1 are legal
  * (LLR = +-inf), as the reference's certainty-1.0 checks produce (hqc.py:689). */
 int scaldpc_bp_set_channel_probs(scaldpc_bp *h, const double *probs);
+/*
+ * A graph that GROWS: the attack loop adds one parity check per oracle answer (hqc.py:885-908,
+ * `H = np.vstack([H, row])`) and decodes every DECODE_EVERY answers on [H | I] (hqc.py:972-980, 680),
+ * where the reference rebuilds the decoder from the dense matrix each time.  Here the decoder lives on:
+ *   scaldpc_bp_append_rows(h, nrows, row_ptr, col_idx, new_n)
+ *       appends `nrows` checks (CSR of the new rows only: row_ptr[0] = 0, columns strictly ascending,
+ *       < new_n) and grows the block length to new_n >= n (the new columns come last -- for [Hin | I]
+ *       each appended row brings its identity column).  Only the new rows are validated; device CSR
+ *       and priors have spare capacity and are appended to; the tables of the row-parallel kernels
+ *       (the single decode() of the attack loop) are updated in place -- one word per new edge while
+ *       the edge's column has a free lane, a moved segment otherwise; what only the 64-codeword-tile
+ *       and LDS kernels need (CSC, degree buckets, their tables) is rebuilt when one of them is next
+ *       used.  Results are those of a decoder freshly built on the grown graph, bit for bit.
+ *   scaldpc_bp_set_channel_probs_tail(h, first, count, probs)
+ *       priors of columns [first, first + count) (float64, as scaldpc_bp_set_channel_probs); the
+ *       columns an append added must be given theirs before the next decode.
+ */
+int scaldpc_bp_append_rows(scaldpc_bp *h, int32_t nrows, const int32_t *row_ptr, const int32_t *col_idx, int32_t new_n);
+int scaldpc_bp_set_channel_probs_tail(scaldpc_bp *h, int32_t first, int32_t count, const double *probs);
 /*
  * Decode `batch` independent inputs, flooding schedule, fp32 messages.
  *   max_iter <= 0 -> n (ldpc convention)

@@ -54,6 +54,10 @@ def _declare(lib):
     lib.scaldpc_bp_last_compacted.restype = C.c_int
     lib.scaldpc_bp_last_stats.argtypes = [vp, p(C.c_int64)]
     lib.scaldpc_bp_last_stats.restype = C.c_int
+    lib.scaldpc_bp_append_rows.argtypes = [vp, C.c_int32, vp, vp, C.c_int32]
+    lib.scaldpc_bp_append_rows.restype = C.c_int
+    lib.scaldpc_bp_set_channel_probs_tail.argtypes = [vp, C.c_int32, C.c_int32, vp]
+    lib.scaldpc_bp_set_channel_probs_tail.restype = C.c_int
     lib.scaldpc_bp_configure.argtypes = [vp, C.c_char_p, C.c_char_p]
     lib.scaldpc_bp_configure.restype = C.c_int
     lib.scaldpc_bp_device_of.argtypes = [vp, p(C.c_int32)]

@@ -115,6 +115,32 @@ class BpDecoder:
         _lib.check(self._lib.scaldpc_bp_set_channel_probs(self._h, _lib.ptr(probs)))
         self.channel_probs = probs
 
+    def append_rows(self, row_ptr, col_idx, new_n, channel_probs_tail):
+        """The graph GROWS (the attack loop's `H = np.vstack([H, row])`, simulate/hqc.py:885-908, where the
+        reference builds a new decoder per decode): append checks to this live decoder.
+
+          row_ptr, col_idx    CSR of the NEW rows only (row_ptr[0] = 0; columns strictly ascending, < new_n)
+          new_n               block length afterwards (>= n: new columns come last -- for H = [Hin | I] every
+                              appended row brings its identity column)
+          channel_probs_tail  priors of the new columns [n, new_n)
+
+        Results of later decodes are those of a decoder freshly built on the grown graph, bit for bit."""
+        rp = np.ascontiguousarray(row_ptr, dtype=np.int32)
+        ci = np.ascontiguousarray(col_idx, dtype=np.int32)
+        tail = np.ascontiguousarray(channel_probs_tail, dtype=np.float64)
+        new_n = int(new_n)
+        if rp.ndim != 1 or rp.size < 1 or ci.ndim != 1 or ci.size != int(rp[-1]):
+            raise ValueError("append_rows expects CSR arrays of the new rows (row_ptr[0] = 0, len(col_idx) = row_ptr[-1])")
+        if tail.shape != (new_n - self.n,):
+            raise ValueError(f"channel_probs_tail must hold the priors of the {new_n - self.n} new columns")
+        old_n = self.n
+        _lib.check(self._lib.scaldpc_bp_append_rows(self._h, rp.size - 1, _lib.ptr(rp), _lib.ptr(ci), new_n))
+        self.m += rp.size - 1
+        self.n = new_n
+        self.graph = None  # (the constructor's graph no longer describes this decoder)
+        _lib.check(self._lib.scaldpc_bp_set_channel_probs_tail(self._h, old_n, new_n - old_n, _lib.ptr(tail)))
+        self.channel_probs = np.concatenate([self.channel_probs, tail])
+
     def _resolve_kind(self, length, input_vector_type=None):
         kind = self._vector_type if input_vector_type is None else _vector_type(input_vector_type)
         if kind == -1:

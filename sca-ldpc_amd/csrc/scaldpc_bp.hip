@@ -87,6 +87,7 @@ struct scaldpc_bp {
     // priors
     float *d_prior = nullptr;
     bool have_prior = false;
+    int prior_n = 0;  // columns whose prior is set (a grown graph needs scaldpc_bp_set_channel_probs_tail for the new ones)
     // workspace (state arrays sized for cap_tiles, messages for cap_group tiles)
     int cap_tiles = 0, cap_group = 0, tile_group = 0;
     float *d_msg = nullptr, *d_scratch = nullptr, *d_post = nullptr;
@@ -126,8 +127,28 @@ struct scaldpc_bp {
     size_t cap_el = 0;
     int *d_el_unsat = nullptr;  // [iteration][64] "some row unsatisfied" flags of the fused early-exit loop
     size_t cap_el_unsat = 0;
-    int *d_el_slots = nullptr, *d_el_winfo = nullptr;  // k_el_var: columns packed into waves of 64 lane slots
-    int el_waves = 0;
+    // k_el_var: columns packed into waves ("bins") of 64 lane slots, each column a segment of `cap` lanes
+    int *d_el_slots = nullptr, *d_el_slot_col = nullptr;  // views into d_el_tab: [2 * 64 * el_cap_bins] and [64 * el_cap_bins] ints
+    int el_waves = 0;     // bins in use
+    int el_cap_bins = 0;  // bins d_el_tab has room for
+    bool el_ok = false;   // the row-parallel path can take this graph (non-empty, no row / column wider than a wave)
+    std::vector<int> h_el_slots, h_el_col;  // host mirrors of the two parts of d_el_tab
+    std::vector<int> seg_slot;            // per column: bin * 64 + first lane of its segment (-1: none)
+    std::vector<unsigned char> seg_cap;   // per column: lanes of its segment
+    int el_open_used = 0;                 // lanes handed out in the last bin
+    // A handle whose graph grows (scaldpc_bp_append_rows): CSR and priors move to allocations of their
+    // own with spare capacity, the row-parallel tables keep a few free lanes per column and are
+    // updated in place; everything only the tile / LDS kernels need (CSC, degree buckets, their
+    // tables) is marked stale and rebuilt from the host mirror when one of those paths is next taken.
+    bool incremental = false, full_stale = false;
+    std::vector<int> hg_col_idx;  // host CSR mirror (incremental handles)
+    int *d_csr_rp = nullptr, *d_csr_ci = nullptr;
+    float *d_prior_buf = nullptr;
+    size_t cap_rows = 0, cap_edges = 0, cap_cols = 0;
+    int ws_m = 0, ws_n = 0;  // what the workspace planes are sized for
+    int *d_pairs = nullptr;  // staging of table updates
+    int *h_pairs = nullptr;  // pinned
+    size_t cap_pairs = 0;
     int *d_graph = nullptr;  // ONE allocation behind the arrays every path needs (CSR, CSC, var list, d_prior: views into it)
     // The tables only one kernel family reads are built on that family's first use -- a decoder
     // that lives for one single decode (hqc.py:694) never pays for the tile kernels' tables, a
@@ -253,22 +274,28 @@ int parity_waves(const scaldpc_bp *h) { return (h->m + 4 * ROWS_PER_WAVE - 1) / 
 
 int ensure_workspace(scaldpc_bp *h, int T, int G, bool want_post, int max_iter)
 {
-    if (T > h->cap_tiles) {
+    if (T > h->cap_tiles || h->m > h->ws_m || h->n > h->ws_n) {
         dev_free(h->d_synd); dev_free(h->d_recv); dev_free(h->d_hard); dev_free(h->d_done);
         dev_free(h->d_conv); dev_free(h->d_unsat); dev_free(h->d_iters); dev_free(h->d_post);
+        T = std::max(T, h->cap_tiles);
         h->cap_tiles = 0;
         h->post_alloc = false;
-        SC_TRY(dev_alloc(&h->d_synd, (size_t)T * h->m));
-        SC_TRY(dev_alloc(&h->d_recv, (size_t)T * h->n));
-        SC_TRY(dev_alloc(&h->d_hard, (size_t)T * h->n));
+        // a growing graph gets planes with room for the rows / columns still to come
+        const int wm = h->incremental ? h->m + h->m / 2 + 64 : h->m, wn = h->incremental ? h->n + h->n / 2 + 64 : h->n;
+        const size_t pw = (size_t)(wm + 4 * ROWS_PER_WAVE - 1) / (4 * ROWS_PER_WAVE) * 4;
+        SC_TRY(dev_alloc(&h->d_synd, (size_t)T * wm));
+        SC_TRY(dev_alloc(&h->d_recv, (size_t)T * wn));
+        SC_TRY(dev_alloc(&h->d_hard, (size_t)T * wn));
         SC_TRY(dev_alloc(&h->d_done, (size_t)T));
         SC_TRY(dev_alloc(&h->d_conv, (size_t)T));
-        SC_TRY(dev_alloc(&h->d_unsat, (size_t)T * parity_waves(h)));
+        SC_TRY(dev_alloc(&h->d_unsat, (size_t)T * pw));
         SC_TRY(dev_alloc(&h->d_iters, (size_t)T * TW));
         h->cap_tiles = T;
+        h->ws_m = wm;
+        h->ws_n = wn;
     }
     if (want_post && !h->post_alloc) {
-        SC_TRY(dev_alloc(&h->d_post, (size_t)h->cap_tiles * h->n * TW));
+        SC_TRY(dev_alloc(&h->d_post, (size_t)h->cap_tiles * h->ws_n * TW));
         h->post_alloc = true;
     }
     (void)G;  // the message arrays are allocated by the path that uses them (ensure_msg / ensure_el)
@@ -388,55 +415,92 @@ int ensure_tile_tables(scaldpc_bp *h)
     return 0;
 }
 
-// Tables of the row-parallel path: whole columns, in degree order, packed into waves of 64 lane slots.
+// ---- tables of the row-parallel path (k_el_var) ------------------------------------------------
+// d_el_tab = [slots: 2 ints per lane slot][slot_col: 1 int per lane slot] for el_cap_bins bins of 64
+// lane slots; h_el mirrors it on the host.
+inline int el_tag(int start, int pos, int cap, bool live) { return start | (pos << 6) | ((cap - 1) << 12) | ((live ? 1 : 0) << 18); }
+inline size_t el_col_off(const scaldpc_bp *h) { return (size_t)128 * h->el_cap_bins; }
+
+// free lanes a column's segment gets on top of its degree: none on a decoder whose graph is fixed
+// (and for the degree-1 columns of an identity block, which never grow); a few on one that grows
+int el_slack(const scaldpc_bp *h, int col, int deg)
+{
+    if (!h->incremental) return 0;
+    if (h->identity_from >= 0 && col >= h->identity_from) return 0;
+    return 2 + deg / 4;
+}
+
+// hands out `cap` neighbouring lanes (a segment never wraps around a bin); returns bin * 64 + start.
+// The host mirrors grow with the bins (dead lanes: no edge, not live); the device table is
+// re-uploaded by the caller when the bins outgrow el_cap_bins.
+int el_alloc_segment(scaldpc_bp *h, int cap)
+{
+    if (h->el_waves == 0 || h->el_open_used + cap > 64) {
+        h->el_waves++;
+        h->el_open_used = 0;
+        if (h->h_el_col.size() < (size_t)64 * h->el_waves) {
+            const size_t lanes = (size_t)64 * (h->el_waves + h->el_waves / 2 + 16), old = h->h_el_col.size();
+            h->h_el_slots.resize(2 * lanes, 0);
+            h->h_el_col.resize(lanes, 0);
+            for (size_t i = old; i < lanes; i++) h->h_el_slots[2 * i] = -1;
+        }
+    }
+    const int slot = (h->el_waves - 1) * 64 + h->el_open_used;
+    h->el_open_used += cap;
+    return slot;
+}
+
+// device copy of the mirrors: [slots: 2 ints per lane][slot_col: 1 int per lane] for el_cap_bins bins
+int el_upload(scaldpc_bp *h)
+{
+    dev_free(h->d_el_tab);
+    h->el_cap_bins = h->incremental ? h->el_waves + h->el_waves / 2 + 64 : h->el_waves;
+    const size_t lanes = (size_t)64 * h->el_cap_bins, used = (size_t)64 * h->el_waves;
+    SC_TRY(dev_alloc(&h->d_el_tab, 3 * lanes));
+    h->d_el_slots = h->d_el_tab;
+    h->d_el_slot_col = h->d_el_tab + el_col_off(h);
+    if (used) {
+        SC_HIP(hipMemcpy(h->d_el_slots, h->h_el_slots.data(), 2 * used * sizeof(int), hipMemcpyHostToDevice));
+        SC_HIP(hipMemcpy(h->d_el_slot_col, h->h_el_col.data(), used * sizeof(int), hipMemcpyHostToDevice));
+    }
+    return 0;
+}
+
+// (re)builds host mirrors + device table from the host graph mirror: columns in degree order (hg_var.list)
+int refresh_full(scaldpc_bp *h);
 int ensure_el_tables(scaldpc_bp *h)
 {
-    if (h->d_el_tab || h->el_waves == 0) return 0;
+    if (h->d_el_tab || !h->el_ok) return 0;
+    SC_TRY(refresh_full(h));  // built from the host's CSC mirror: bring it up to date with appended rows first
     const HostBuckets &hv = h->hg_var;
     const int *cdeg = h->hg_cdeg.data(), *col_ptr = h->hg_col_ptr.data(), *csc_edge = h->hg_csc_edge.data();
-    const size_t o_slots = 0, o_winfo = ((size_t)h->el_waves * 128 + 63) / 64 * 64, total = o_winfo + (size_t)h->el_waves * 2;
-    int *host = stage_buffer(total);
-    if (!host) return fail(SCALDPC_ENOMEM, "out of host memory");
-    int *slots = host + o_slots, *winfo = host + o_winfo;
-    int w = -1, used = 64;
-    auto pad_wave = [&]() {  // empty slots: no edge, not valid
-        if (w >= 0)
-            for (; used < 64; used++) {
-                slots[2 * ((size_t)w * 64 + used)] = -1;
-                slots[2 * ((size_t)w * 64 + used) + 1] = 0;
-            }
-    };
+    h->seg_slot.assign(h->n, -1);
+    h->seg_cap.assign(h->n, 0);
+    h->el_waves = 0;
+    h->el_open_used = 0;
+    h->h_el_slots.clear();
+    h->h_el_col.clear();
     for (size_t i = 0; i < hv.list.size(); i++) {
-        const int v = hv.list[i], d = cdeg[v], need = std::max(d, 1);
-        if (used + need > 64) {
-            pad_wave();
-            w++;
-            used = 0;
-            winfo[2 * w + 0] = 0;
-            winfo[2 * w + 1] = (int)i;
-        }
-        winfo[2 * w] = std::max(winfo[2 * w], d);
+        const int v = hv.list[i], d = cdeg[v];
+        const int cap = std::min(64, std::max(d, 1) + el_slack(h, v, d));
+        const int s0 = el_alloc_segment(h, cap), start = s0 & 63;
+        h->seg_slot[v] = s0;
+        h->seg_cap[v] = (unsigned char)cap;
         const int *ce = csc_edge + col_ptr[v];
-        int *sl = slots + 2 * ((size_t)w * 64 + used);
-        const int tag = used | (d << 13) | (1 << 20);
-        for (int k = 0; k < need; k++) {
-            sl[2 * k] = d ? ce[k] : -1;
-            sl[2 * k + 1] = tag | (k << 6);
+        for (int k = 0; k < cap; k++) {
+            h->h_el_slots[2 * (size_t)(s0 + k)] = k < d ? ce[k] : -1;
+            h->h_el_slots[2 * (size_t)(s0 + k) + 1] = el_tag(start, k, cap, true);
         }
-        used += need;
+        h->h_el_col[s0] = v;
     }
-    pad_wave();
-    SC_TRY(upload_table(&h->d_el_tab, host, total));
-    h->d_el_slots = h->d_el_tab + o_slots;
-    h->d_el_winfo = h->d_el_tab + o_winfo;
-    return 0;
+    return el_upload(h);
 }
 
 // message array of the tile path, G tiles
 int ensure_msg(scaldpc_bp *h, int G)
 {
     SC_TRY(ensure_tile_tables(h));
-    if (G > h->cap_group) {
+    if (G > h->cap_group) {  // (append_rows resets cap_group: the arrays are sized by E)
         dev_free(h->d_msg); dev_free(h->d_scratch);
         h->cap_group = 0;
         SC_TRY(dev_alloc(&h->d_msg, (size_t)G * h->E * TW));
@@ -468,7 +532,7 @@ int ensure_el(scaldpc_bp *h, int nb)
 // tile, SCALDPC_PATH=stream disables the path (tests pin either).
 int el_limit(const scaldpc_bp *h, int method)
 {
-    if (h->el_waves == 0) return 0;  // empty graph, or a row / column wider than a wave
+    if (!h->el_ok) return 0;  // empty graph, or a row / column wider than a wave
     int lim = method == SCALDPC_BP_MIN_SUM ? 6 : 4;
     if (h->kn.el_max >= 0) lim = h->kn.el_max;
     if (h->kn.path == Knobs::STREAM) lim = 0;
@@ -578,8 +642,8 @@ int launch_el_var(scaldpc_bp *h, int nb, float *post_g, u64 *hard_g, u64 *done_g
     // grid.x a multiple of 8: block x lands on the same XCD for every codeword row, so an XCD's L2
     // keeps its share of the slot table
     const unsigned gx = (unsigned)(((h->el_waves + 3) / 4 + 7) / 8 * 8);
-    hipLaunchKernelGGL(k_el_var, dim3(gx, nb), dim3(256), 0, s, (const int2 *)h->d_el_slots, (const int2 *)h->d_el_winfo,
-                       h->d_var_list, h->el_waves, h->d_prior, h->d_emsg, post_g, hard_g, done_g, skip_done, h->E,
+    hipLaunchKernelGGL(k_el_var, dim3(gx, nb), dim3(256), 0, s, (const int2 *)h->d_el_slots, h->d_el_slot_col,
+                       h->el_waves, h->d_prior, h->d_emsg, post_g, hard_g, done_g, skip_done, h->E,
                        write_out, unsat_prev, it_prev, conv_g, iters_g, remaining_prev);
     LAUNCH_CHECK();
     return 0;
@@ -949,9 +1013,6 @@ int run_core(scaldpc_bp *h, int batch, int T, int G, int max_iter, int method, f
 
 }  // namespace
 
-// ===========================================================================
-// C ABI
-// ===========================================================================
 #include <chrono>
 #define TMARK(name)                                                                                   \
     do {                                                                                              \
@@ -968,6 +1029,155 @@ static std::chrono::steady_clock::time_point &tmark_last()
     static thread_local std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
     return t;
 }
+
+namespace {
+
+// Everything that depends on the WHOLE graph, from the host CSR and the node degrees: degree
+// buckets, CSC permutation, identity block, and the device copy of the arrays every path needs --
+// views into ONE allocation filled by ONE copy: the attack loop builds a new decoder per decode
+// (hqc.py:694), so construction is on its critical path (a dozen hipMalloc + synchronous hipMemcpy
+// pairs cost more than the decode).  The per-kernel-family tables follow on first use
+// (ensure_tile_tables / ensure_el_tables).  Used by scaldpc_bp_create and, on a handle whose graph
+// has grown, by refresh_full (there CSR and priors already live in buffers of their own).
+// Consumes cdeg.
+int finish_graph(scaldpc_bp *h, const int *row_ptr, const int *col_idx, const std::vector<int> &rdeg, std::vector<int> &cdeg)
+{
+    const int m = h->m, n = h->n;
+    const long nnz = h->E;
+    h->max_row_deg = m ? *std::max_element(rdeg.begin(), rdeg.end()) : 0;
+    h->max_col_deg = *std::max_element(cdeg.begin(), cdeg.end());
+    static const int vb[] = {1, 2, 4, 8, 16, 32, 64};
+    static const int rb[] = {2, 4, 8, 16, 32, 64};
+    HostBuckets hv, hr;
+    build_buckets(cdeg, vb, 7, true, hv);
+    build_buckets(rdeg, rb, 6, false, hr);
+    TMARK("buckets");
+    h->var_bk = hv.bk;
+    h->row_bk = hr.bk;
+    h->need_scratch = hv.has_generic || hr.has_generic;
+    h->identity_from = -1;
+    if (n > m) {  // H = [Hin | I_m]?  (what hqc.decode builds, hqc.py:680)
+        bool ident = true;
+        for (int r = 0; r < m && ident; r++) {
+            const int j = n - m + r;
+            ident = cdeg[j] == 1 && row_ptr[r + 1] > row_ptr[r] && col_idx[row_ptr[r + 1] - 1] == j;
+        }
+        h->identity_from = ident ? n - m : -1;
+    }
+    h->el_ok = nnz > 0 && h->max_row_deg <= 64 && h->max_col_deg <= 64;  // the row-parallel path can take this graph
+    const bool own_csr = h->incremental;  // CSR and priors already live in growable buffers of their own
+    size_t total = 0;
+    auto reserve = [&](size_t cnt) {  // 256-byte aligned sections
+        const size_t off = total;
+        total += (cnt + 63) / 64 * 64;
+        return off;
+    };
+    const size_t o_row_ptr = own_csr ? 0 : reserve((size_t)m + 1), o_col_idx = own_csr ? 0 : reserve((size_t)nnz);
+    const size_t o_col_ptr = reserve((size_t)n + 1), o_csc_edge = reserve((size_t)nnz), o_var_list = reserve(hv.list.size());
+    const size_t o_prior = own_csr ? 0 : reserve((size_t)n);
+    int *const host = stage_buffer(total);  // not cleared: every word a kernel reads is written below
+    if (!host) return fail(SCALDPC_ENOMEM, "out of host memory");
+    TMARK("reserve");
+    if (!own_csr) {
+        std::copy(row_ptr, row_ptr + m + 1, host + o_row_ptr);
+        std::copy(col_idx, col_idx + nnz, host + o_col_idx);
+    }
+    // CSC permutation: edges grouped by column, ascending row (row-major scan keeps rows ascending)
+    int *col_ptr = host + o_col_ptr, *csc_edge = host + o_csc_edge;
+    {
+        col_ptr[0] = 0;
+        for (int j = 0; j < n; j++) col_ptr[j + 1] = col_ptr[j] + cdeg[j];
+        std::vector<int> cursor(col_ptr, col_ptr + n);
+        for (int e = 0; e < (int)nnz; e++) csc_edge[cursor[col_idx[e]]++] = e;
+    }
+    std::copy(hv.list.begin(), hv.list.end(), host + o_var_list);
+    TMARK("csc");
+    SC_TRY(dev_alloc(&h->d_graph, total));
+    if (hipMemcpy(h->d_graph, host, total * sizeof(int), hipMemcpyHostToDevice) != hipSuccess)
+        return fail(SCALDPC_EHIP, "graph upload failed");
+    TMARK("upload");
+    // what the lazy table builders need
+    if (!own_csr) h->hg_row_ptr.assign(row_ptr, row_ptr + m + 1);
+    h->hg_col_ptr.assign(col_ptr, col_ptr + n + 1);
+    h->hg_csc_edge.assign(csc_edge, csc_edge + nnz);
+    h->hg_cdeg.swap(cdeg);
+    h->hg_var = std::move(hv);
+    h->hg_row = std::move(hr);
+    TMARK("keep");
+    if (!own_csr) {
+        h->d_row_ptr = h->d_graph + o_row_ptr;
+        h->d_col_idx = h->d_graph + o_col_idx;
+        h->d_prior = (float *)(h->d_graph + o_prior);
+    }
+    h->d_col_ptr = h->d_graph + o_col_ptr;
+    h->d_csc_edge = h->d_graph + o_csc_edge;
+    h->d_var_list = h->d_graph + o_var_list;
+    return 0;
+}
+
+// ---- a graph that grows (scaldpc_bp_append_rows) -------------------------------------------------
+// First append: CSR and priors leave the construction-time allocation for buffers with spare
+// capacity; the host keeps the CSR (col_idx is recovered from the CSC mirror); the row-parallel
+// tables are dropped and come back with free lanes on the next decode.
+int make_incremental(scaldpc_bp *h)
+{
+    if (h->incremental) return 0;
+    const size_t rows = (size_t)h->m + 1, edges = (size_t)h->E, cols = (size_t)h->n;
+    h->cap_rows = rows + rows / 2 + 256;
+    h->cap_edges = edges + edges / 2 + 4096;
+    h->cap_cols = cols + cols / 2 + 256;
+    SC_TRY(dev_alloc(&h->d_csr_rp, h->cap_rows));
+    SC_TRY(dev_alloc(&h->d_csr_ci, h->cap_edges));
+    SC_TRY(dev_alloc(&h->d_prior_buf, h->cap_cols));
+    SC_HIP(hipMemcpy(h->d_csr_rp, h->d_row_ptr, rows * sizeof(int), hipMemcpyDeviceToDevice));
+    if (edges) SC_HIP(hipMemcpy(h->d_csr_ci, h->d_col_idx, edges * sizeof(int), hipMemcpyDeviceToDevice));
+    SC_HIP(hipMemcpy(h->d_prior_buf, h->d_prior, cols * sizeof(float), hipMemcpyDeviceToDevice));
+    h->d_row_ptr = h->d_csr_rp;
+    h->d_col_idx = h->d_csr_ci;
+    h->d_prior = h->d_prior_buf;
+    h->hg_col_idx.resize(edges);
+    for (int j = 0; j < h->n; j++)
+        for (int k = h->hg_col_ptr[j]; k < h->hg_col_ptr[j + 1]; k++) h->hg_col_idx[h->hg_csc_edge[k]] = j;
+    h->incremental = true;
+    dev_free(h->d_el_tab);  // rebuilt with free lanes per column on the next use
+    h->d_el_slots = h->d_el_slot_col = nullptr;
+    return 0;
+}
+
+template <typename T>
+int grow_keep(T **p, size_t *cap, size_t used, size_t need)
+{
+    if (need <= *cap) return 0;
+    const size_t ncap = need + need / 2 + 256;
+    T *q = nullptr;
+    SC_TRY(dev_alloc(&q, ncap));
+    if (used) SC_HIP(hipMemcpy(q, *p, used * sizeof(T), hipMemcpyDeviceToDevice));
+    dev_free(*p);
+    *p = q;
+    *cap = ncap;
+    return 0;
+}
+
+// The tile / LDS kernels' view of a grown graph: CSC, degree buckets, identity block, device CSC
+// arrays, and (lazily, on their first use) the tile tables.  O(E) on the host, as a construction.
+int refresh_full(scaldpc_bp *h)
+{
+    if (!h->full_stale) return 0;
+    std::vector<int> rdeg(h->m), cdeg(h->hg_cdeg);
+    for (int r = 0; r < h->m; r++) rdeg[r] = h->hg_row_ptr[r + 1] - h->hg_row_ptr[r];
+    dev_free(h->d_graph);
+    dev_free(h->d_tile_tab);
+    h->d_var_meta = h->d_csc_list = h->d_row_list = nullptr;
+    SC_TRY(finish_graph(h, h->hg_row_ptr.data(), h->hg_col_idx.data(), rdeg, cdeg));
+    h->full_stale = false;
+    return 0;
+}
+
+}  // namespace
+
+// ===========================================================================
+// C ABI
+// ===========================================================================
 
 extern "C" {
 
@@ -998,93 +1208,14 @@ int scaldpc_bp_create(int32_t m, int32_t n, int64_t nnz, const int32_t *row_ptr,
     h->m = m;
     h->n = n;
     h->E = nnz;
-    h->max_row_deg = m ? *std::max_element(rdeg.begin(), rdeg.end()) : 0;
-    h->max_col_deg = *std::max_element(cdeg.begin(), cdeg.end());
-
     TMARK("validate");
-    static const int vb[] = {1, 2, 4, 8, 16, 32, 64};
-    static const int rb[] = {2, 4, 8, 16, 32, 64};
-    HostBuckets hv, hr;
-    build_buckets(cdeg, vb, 7, true, hv);
-    build_buckets(rdeg, rb, 6, false, hr);
-    TMARK("buckets");
-    h->var_bk = hv.bk;
-    h->row_bk = hr.bk;
-    h->need_scratch = hv.has_generic || hr.has_generic;
-    if (n > m) {  // H = [Hin | I_m]?  (what hqc.decode builds, hqc.py:680)
-        bool ident = true;
-        for (int r = 0; r < m && ident; r++) {
-            const int j = n - m + r;
-            ident = cdeg[j] == 1 && row_ptr[r + 1] > row_ptr[r] && col_idx[row_ptr[r + 1] - 1] == j;
-        }
-        h->identity_from = ident ? n - m : -1;
-    }
-
-    // The arrays every path needs are views into ONE allocation filled by ONE copy: the attack loop
-    // builds a new decoder per decode (hqc.py:694), so construction is on its critical path (a dozen
-    // hipMalloc + synchronous hipMemcpy pairs cost more than the decode).  The per-kernel-family
-    // tables follow on first use (ensure_tile_tables / ensure_el_tables).
-    if (nnz > 0 && h->max_row_deg <= 64 && h->max_col_deg <= 64) {  // row-parallel path possible: count its waves
-        int used = 0, el_waves = 0;
-        for (size_t i = 0; i < hv.list.size(); i++) {
-            const int need = std::max(cdeg[hv.list[i]], 1);
-            if (used + need > 64) used = 0;
-            if (used == 0) el_waves++;
-            used += need;
-        }
-        h->el_waves = el_waves;
-    }
-    size_t total = 0;
-    auto reserve = [&](size_t cnt) {  // 256-byte aligned sections
-        const size_t off = total;
-        total += (cnt + 63) / 64 * 64;
-        return off;
-    };
-    const size_t o_row_ptr = reserve((size_t)m + 1), o_col_idx = reserve((size_t)nnz), o_col_ptr = reserve((size_t)n + 1);
-    const size_t o_csc_edge = reserve((size_t)nnz), o_var_list = reserve(hv.list.size());
-    const size_t o_prior = reserve((size_t)n);
-    int *const host = stage_buffer(total);  // not cleared: every word a kernel reads is written below
-    if (!host) {
-        delete h;
-        return fail(SCALDPC_ENOMEM, "out of host memory");
-    }
-    TMARK("reserve");
-    std::copy(row_ptr, row_ptr + m + 1, host + o_row_ptr);
-    std::copy(col_idx, col_idx + nnz, host + o_col_idx);
-    // CSC permutation: edges grouped by column, ascending row (row-major scan keeps rows ascending)
-    int *col_ptr = host + o_col_ptr, *csc_edge = host + o_csc_edge;
-    {
-        col_ptr[0] = 0;
-        for (int j = 0; j < n; j++) col_ptr[j + 1] = col_ptr[j] + cdeg[j];
-        std::vector<int> cursor(col_ptr, col_ptr + n);
-        for (int e = 0; e < (int)nnz; e++) csc_edge[cursor[col_idx[e]]++] = e;
-    }
-    std::copy(hv.list.begin(), hv.list.end(), host + o_var_list);
-    TMARK("csc");
-    int rc = dev_alloc(&h->d_graph, total);
-    if (!rc && hipMemcpy(h->d_graph, host, total * sizeof(int), hipMemcpyHostToDevice) != hipSuccess)
-        rc = fail(SCALDPC_EHIP, "graph upload failed");
-    TMARK("upload");
-    // what the lazy table builders need
-    h->hg_row_ptr.assign(row_ptr, row_ptr + m + 1);
-    h->hg_col_ptr.assign(col_ptr, col_ptr + n + 1);
-    h->hg_csc_edge.assign(csc_edge, csc_edge + nnz);
-    h->hg_cdeg.swap(cdeg);
-    h->hg_var = std::move(hv);
-    h->hg_row = std::move(hr);
-    TMARK("keep");
+    int rc = finish_graph(h, row_ptr, col_idx, rdeg, cdeg);
     if (!rc) rc = stream_acquire(&h->own_stream, &h->device);
     TMARK("stream");
     if (rc) {
         scaldpc_bp_destroy(h);
         return rc;
     }
-    h->d_row_ptr = h->d_graph + o_row_ptr;
-    h->d_col_idx = h->d_graph + o_col_idx;
-    h->d_col_ptr = h->d_graph + o_col_ptr;
-    h->d_csc_edge = h->d_graph + o_csc_edge;
-    h->d_var_list = h->d_graph + o_var_list;
-    h->d_prior = (float *)(h->d_graph + o_prior);
     *out = h;
     return 0;
 }
@@ -1113,6 +1244,208 @@ int scaldpc_bp_set_channel_probs(scaldpc_bp *h, const double *probs)
     h->h_probs.assign(probs, probs + h->n);
     h->thr_valid = false;
     h->have_prior = true;
+    h->prior_n = h->n;
+    return 0;
+}
+
+int scaldpc_bp_set_channel_probs_tail(scaldpc_bp *h, int32_t first, int32_t count, const double *probs)
+{
+    if (!h || (count > 0 && !probs)) return fail(SCALDPC_EINVAL, "NULL argument");
+    std::lock_guard<std::mutex> lk(h->mu);
+    DeviceGuard dg(h->device);
+    if (first < 0 || count < 0 || (long)first + count > h->n)
+        return fail(SCALDPC_EINVAL, "columns [%d, %d) are outside the graph (n = %d)", first, first + count, h->n);
+    if (first > h->prior_n) return fail(SCALDPC_EINVAL, "priors of columns [%d, %d) are still unset", h->prior_n, first);
+    if (count == 0) return 0;
+    if (h->async_used) SC_HIP(hipDeviceSynchronize());
+    std::vector<float> llr(count);
+    float last_p = 0.0f, last_llr = 0.0f;
+    for (int j = 0; j < count; j++) {
+        if (!(probs[j] >= 0.0 && probs[j] <= 1.0))
+            return fail(SCALDPC_EINVAL, "channel_probs[%d] = %g is not a probability", first + j, probs[j]);
+        const float p = (float)probs[j];  // same expression as scaldpc_bp_set_channel_probs
+        if (j == 0 || p != last_p) {
+            last_p = p;
+            last_llr = logf((1.0f - p) / p);
+        }
+        llr[j] = last_llr;
+    }
+    SC_HIP(hipMemcpy(h->d_prior + first, llr.data(), sizeof(float) * count, hipMemcpyHostToDevice));
+    h->h_probs.resize(h->n, 0.0);
+    std::copy(probs, probs + count, h->h_probs.begin() + first);
+    h->thr_valid = false;
+    h->prior_n = std::max(h->prior_n, first + count);
+    h->have_prior = true;
+    return 0;
+}
+
+int scaldpc_bp_append_rows(scaldpc_bp *h, int32_t nrows, const int32_t *row_ptr, const int32_t *col_idx, int32_t new_n)
+{
+    if (!h || nrows < 0 || (nrows > 0 && !row_ptr)) return fail(SCALDPC_EINVAL, "bad arguments");
+    std::lock_guard<std::mutex> lk(h->mu);
+    DeviceGuard dg(h->device);
+    CacheBypass guard(h->async_used);
+    if (new_n < h->n) return fail(SCALDPC_EINVAL, "new_n = %d is smaller than the current block length %d", new_n, h->n);
+    const long add = nrows ? row_ptr[nrows] : 0;
+    if (nrows && (row_ptr[0] != 0 || add < 0 || (add && !col_idx))) return fail(SCALDPC_EINVAL, "row_ptr does not start at 0");
+    if ((long)h->E + add > 0x7fffffffL) return fail(SCALDPC_EINVAL, "nnz too large");
+    // only the NEW rows are validated; the old ones were when they came in
+    for (int r = 0; r < nrows; r++) {
+        if (row_ptr[r + 1] < row_ptr[r]) return fail(SCALDPC_EINVAL, "row_ptr not monotone at appended row %d", r);
+        for (int e = row_ptr[r]; e < row_ptr[r + 1]; e++) {
+            if (col_idx[e] < 0 || col_idx[e] >= new_n) return fail(SCALDPC_EINVAL, "col_idx out of range at appended edge %d", e);
+            if (e > row_ptr[r] && col_idx[e] <= col_idx[e - 1])
+                return fail(SCALDPC_EINVAL, "col_idx not strictly ascending in appended row %d", r);
+        }
+    }
+    if (nrows == 0 && new_n == h->n) return 0;
+    if (h->async_used) SC_HIP(hipDeviceSynchronize());  // the tables below may still be read by work in flight
+    SC_TRY(make_incremental(h));
+    hipStream_t s = h->own_stream;
+    const int m0 = h->m, n0 = h->n;
+    const long E0 = h->E;
+    SC_TRY(grow_keep(&h->d_csr_rp, &h->cap_rows, (size_t)m0 + 1, (size_t)m0 + 1 + nrows));
+    SC_TRY(grow_keep(&h->d_csr_ci, &h->cap_edges, (size_t)E0, (size_t)E0 + add));
+    SC_TRY(grow_keep(&h->d_prior_buf, &h->cap_cols, (size_t)n0, (size_t)new_n));
+    h->d_row_ptr = h->d_csr_rp;
+    h->d_col_idx = h->d_csr_ci;
+    h->d_prior = h->d_prior_buf;
+
+    // ---- host mirror: CSR, column degrees ------------------------------------------------------
+    h->hg_row_ptr.reserve((size_t)m0 + 1 + nrows);
+    for (int r = 0; r < nrows; r++) h->hg_row_ptr.push_back((int)(E0 + row_ptr[r + 1]));
+    h->hg_col_idx.insert(h->hg_col_idx.end(), col_idx, col_idx + add);
+    h->hg_cdeg.resize(new_n, 0);
+    for (int r = 0; r < nrows; r++) h->max_row_deg = std::max(h->max_row_deg, row_ptr[r + 1] - row_ptr[r]);
+
+    // ---- row-parallel tables, in place: one slot word per new edge while its column has a free lane
+    const bool had_tables = h->d_el_tab != nullptr;
+    std::vector<int> dirty_slot, dirty_col;  // indices into h_el_slots / h_el_col that changed
+    bool el_alive = had_tables;
+    if (had_tables) {
+        h->seg_slot.resize(new_n, -1);
+        h->seg_cap.resize(new_n, 0);
+    }
+    auto set_slot = [&](size_t i, int v) {
+        if (h->h_el_slots[i] != v) {
+            h->h_el_slots[i] = v;
+            dirty_slot.push_back((int)i);
+        }
+    };
+    auto new_segment = [&](int c, int cap, const int *edges, int d) {  // writes a whole segment
+        const int s0 = el_alloc_segment(h, cap), start = s0 & 63;
+        for (int k = 0; k < cap; k++) {
+            set_slot(2 * (size_t)(s0 + k), k < d ? edges[k] : -1);
+            set_slot(2 * (size_t)(s0 + k) + 1, el_tag(start, k, cap, true));
+        }
+        if (h->h_el_col[s0] != c) {
+            h->h_el_col[s0] = c;
+            dirty_col.push_back(s0);
+        }
+        h->seg_slot[c] = s0;
+        h->seg_cap[c] = (unsigned char)cap;
+    };
+    int edges_tmp[64];
+    for (long i = 0; i < add; i++) {
+        const int c = col_idx[i], e = (int)(E0 + i);
+        const int d_old = h->hg_cdeg[c]++;
+        h->max_col_deg = std::max(h->max_col_deg, d_old + 1);
+        if (!el_alive) continue;
+        if (d_old + 1 > 64) {  // a column wider than a wave: the row-parallel path is gone for this graph
+            el_alive = false;
+            continue;
+        }
+        if (h->seg_slot[c] < 0) {  // a column that came with these rows
+            edges_tmp[0] = e;
+            new_segment(c, std::min(64, 1 + el_slack(h, c, 1)), edges_tmp, 1);
+        } else if (d_old < h->seg_cap[c]) {
+            set_slot(2 * (size_t)(h->seg_slot[c] + d_old), e);
+        } else {  // the segment is full: the column moves to a larger one, its old lanes go dead
+            const int s_old = h->seg_slot[c], cap_old = h->seg_cap[c];
+            for (int k = 0; k < d_old; k++) edges_tmp[k] = h->h_el_slots[2 * (size_t)(s_old + k)];
+            edges_tmp[d_old] = e;
+            for (int k = 0; k < cap_old; k++) {
+                set_slot(2 * (size_t)(s_old + k), -1);
+                set_slot(2 * (size_t)(s_old + k) + 1, 0);
+            }
+            new_segment(c, std::min(64, d_old + 1 + el_slack(h, c, d_old + 1)), edges_tmp, d_old + 1);
+        }
+    }
+    if (el_alive)
+        for (int c = n0; c < new_n; c++)  // new columns no appended row touches: isolated variables still have a posterior
+            if (h->seg_slot[c] < 0) new_segment(c, 1, edges_tmp, 0);
+
+    h->m = m0 + nrows;
+    h->n = new_n;
+    h->E = E0 + add;
+    h->el_ok = h->E > 0 && h->max_row_deg <= 64 && h->max_col_deg <= 64;
+    if (had_tables && (!el_alive || !h->el_ok)) {
+        dev_free(h->d_el_tab);
+        h->d_el_slots = h->d_el_slot_col = nullptr;
+        el_alive = false;
+    }
+
+    // ---- device: CSR tails, table words -----------------------------------------------------------
+    std::sort(dirty_slot.begin(), dirty_slot.end());
+    dirty_slot.erase(std::unique(dirty_slot.begin(), dirty_slot.end()), dirty_slot.end());
+    std::sort(dirty_col.begin(), dirty_col.end());
+    dirty_col.erase(std::unique(dirty_col.begin(), dirty_col.end()), dirty_col.end());
+    const bool reupload = el_alive && h->el_waves > h->el_cap_bins;  // the bins outgrew the device table
+    const size_t npairs = (el_alive && !reupload) ? dirty_slot.size() + dirty_col.size() : 0;
+    const size_t stage_ints = (size_t)nrows + add + 2 * npairs;
+    if (stage_ints > h->cap_pairs) {
+        cached_free(h->h_pairs);
+        dev_free(h->d_pairs);
+        h->h_pairs = nullptr;
+        h->cap_pairs = 0;
+        const size_t want = stage_ints + stage_ints / 2 + 1024;
+        SC_TRY(cached_alloc((void **)&h->h_pairs, want * sizeof(int), true));
+        SC_TRY(dev_alloc(&h->d_pairs, want));
+        h->cap_pairs = want;
+    }
+    int *st = h->h_pairs;
+    for (int r = 0; r < nrows; r++) st[r] = (int)(E0 + row_ptr[r + 1]);
+    std::copy(col_idx, col_idx + add, st + nrows);
+    if (nrows) SC_HIP(hipMemcpyAsync(h->d_row_ptr + m0 + 1, st, sizeof(int) * nrows, hipMemcpyHostToDevice, s));
+    if (add) SC_HIP(hipMemcpyAsync(h->d_col_idx + E0, st + nrows, sizeof(int) * add, hipMemcpyHostToDevice, s));
+    if (reupload) {
+        SC_TRY(el_upload(h));
+    } else if (npairs) {
+        int *pp = st + nrows + add;
+        const int col_base = (int)el_col_off(h);
+        size_t q = 0;
+        for (int i : dirty_slot) {
+            pp[2 * q] = i;
+            pp[2 * q + 1] = h->h_el_slots[i];
+            q++;
+        }
+        for (int i : dirty_col) {
+            pp[2 * q] = col_base + i;
+            pp[2 * q + 1] = h->h_el_col[i];
+            q++;
+        }
+        SC_HIP(hipMemcpyAsync(h->d_pairs, pp, sizeof(int) * 2 * npairs, hipMemcpyHostToDevice, s));
+        hipLaunchKernelGGL(k_apply_pairs, dim3((unsigned)((npairs + 255) / 256)), dim3(256), 0, s, h->d_el_tab,
+                           (const int2 *)h->d_pairs, (int)npairs);
+        LAUNCH_CHECK();
+    }
+    SC_HIP(hipStreamSynchronize(s));
+
+    // ---- what was sized or derived for the old graph ------------------------------------------------
+    h->full_stale = true;  // CSC, degree buckets, identity block, tile tables: rebuilt when the tile / LDS kernels are next needed
+    h->h_probs.resize(new_n, 0.0);
+    h->thr_valid = false;
+    dev_free(h->d_thr);
+    dev_free(h->d_msg);
+    dev_free(h->d_scratch);
+    h->cap_group = 0;
+    for (auto &L : h->lv) {
+        dev_free(L.synd); dev_free(L.hard); dev_free(L.done); dev_free(L.conv); dev_free(L.unsat);
+        dev_free(L.iters); dev_free(L.ids); dev_free(L.post);
+        L.cap_tiles = 0;
+        L.cap_post = 0;
+    }
+    h->last_group = 0;
     return 0;
 }
 
@@ -1156,7 +1489,8 @@ int scaldpc_bp_decode_batch(scaldpc_bp *h, const uint8_t *in, int32_t input_kind
     if (!(alpha >= 0.0f)) return fail(SCALDPC_EINVAL, "ms_scaling_factor must be >= 0");
     std::lock_guard<std::mutex> lk(h->mu);
     DeviceGuard dg(h->device);
-    if (!h->have_prior) return fail(SCALDPC_EINVAL, "channel probabilities not set");
+    if (!h->have_prior || h->prior_n < h->n)
+        return fail(SCALDPC_EINVAL, "channel probabilities not set (columns [%d, %d))", h->have_prior ? h->prior_n : 0, h->n);
     if (max_iter <= 0) max_iter = h->n;
     const bool dev_io = flags & SCALDPC_F_DEVICE_IO;
     const bool early = flags & SCALDPC_F_EARLY_EXIT;
@@ -1174,6 +1508,10 @@ int scaldpc_bp_decode_batch(scaldpc_bp *h, const uint8_t *in, int32_t input_kind
     // Small graph: the LDS-resident single-launch decoder (k_bp_small).
     const size_t small_lds = (size_t)2 * h->E * sizeof(float) + (size_t)2 * h->n + h->m + 64;
     const bool small_fits = small_lds <= 60 * 1024 && h->E > 0;
+    if (h->full_stale) {  // rows were appended: only the row-parallel path is up to date
+        const bool small_path = small_fits && h->kn.path != Knobs::STREAM && h->kn.path != Knobs::EDGE;
+        if (small_path || !(T == 1 && batch <= el_limit(h, method))) SC_TRY(refresh_full(h));
+    }
     if (h->kn.path == Knobs::LDS && !small_fits)  // "stream" / "edge" / "lds" pin a path (tests)
         return fail(SCALDPC_EINVAL, "SCALDPC_PATH=lds but the graph needs %zu B of LDS", small_lds);
     if (small_fits && h->kn.path != Knobs::STREAM && h->kn.path != Knobs::EDGE) {
@@ -1365,8 +1703,10 @@ int scaldpc_mc_fer_run(scaldpc_bp *h, int64_t first_trial, int32_t batch, uint64
     std::lock_guard<std::mutex> lk(h->mu);
     DeviceGuard dg(h->device);
     CacheBypass guard(h->async_used);
-    if (!h->have_prior) return fail(SCALDPC_EINVAL, "channel probabilities not set");
+    if (!h->have_prior || h->prior_n < h->n)
+        return fail(SCALDPC_EINVAL, "channel probabilities not set (columns [%d, %d))", h->have_prior ? h->prior_n : 0, h->n);
     if (max_iter <= 0) max_iter = h->n;
+    SC_TRY(refresh_full(h));
     const bool dev_io = flags & SCALDPC_F_DEVICE_IO, early = flags & SCALDPC_F_EARLY_EXIT;
     hipStream_t s = stream ? (hipStream_t)stream : h->own_stream;
     const int T = (batch + TW - 1) / TW;
@@ -1403,7 +1743,9 @@ int scaldpc_mc_hqc_run(scaldpc_bp *h, int32_t omega, double eps, int64_t first_t
     std::lock_guard<std::mutex> lk(h->mu);
     DeviceGuard dg(h->device);
     CacheBypass guard(h->async_used);
-    if (!h->have_prior) return fail(SCALDPC_EINVAL, "channel probabilities not set");
+    if (!h->have_prior || h->prior_n < h->n)
+        return fail(SCALDPC_EINVAL, "channel probabilities not set (columns [%d, %d))", h->have_prior ? h->prior_n : 0, h->n);
+    SC_TRY(refresh_full(h));
     if (h->identity_from < 0) return fail(SCALDPC_EINVAL, "parity-check matrix is not of the form [Hin | I] (hqc.py:680)");
     const int N = h->identity_from;
     if (omega < 0 || omega > N) return fail(SCALDPC_EINVAL, "omega must be in [0, N]");
@@ -1593,7 +1935,9 @@ void scaldpc_bp_destroy(scaldpc_bp *h)
     // them for the next handle.  The guard must be in place BEFORE the first block is released.
     CacheBypass guard(h->async_used);
     if (h->async_used) (void)hipDeviceSynchronize();
-    dev_free(h->d_graph);  // graph arrays and d_prior are views into it
+    dev_free(h->d_graph);  // graph arrays and d_prior are views into it (until the graph grows)
+    dev_free(h->d_csr_rp); dev_free(h->d_csr_ci); dev_free(h->d_prior_buf); dev_free(h->d_pairs);
+    cached_free(h->h_pairs);
     dev_free(h->d_tile_tab);
     dev_free(h->d_el_tab);
     dev_free(h->d_msg); dev_free(h->d_scratch); dev_free(h->d_post);

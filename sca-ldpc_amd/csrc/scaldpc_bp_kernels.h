@@ -832,10 +832,16 @@ __global__ __launch_bounds__(256) void k_el_check(const int *__restrict__ row_pt
     }
 }
 
-// Variable nodes, lane = EDGE OF A COLUMN.  The host packs whole columns (in degree order) into
-// waves of 64 lane slots (a column of degree d takes max(d, 1) neighbouring slots); a slot is
-// {edge id or -1, first lane of the column's segment | position << 6 | degree << 13 | valid << 20},
-// a wave additionally knows {its largest degree, the index of its first column in `cols`}.
+// Variable nodes, lane = EDGE OF A COLUMN.  The host packs whole columns into waves of 64 lane
+// slots: a column owns a SEGMENT of `cap` neighbouring lanes, cap >= max(degree, 1), of which the
+// first `degree` hold its edges in ascending row order.  A slot is
+//   {edge id or -1,  start | pos << 6 | (cap - 1) << 12 | live << 18}
+// (start = first lane of the segment, pos = this lane's position in it, live = the segment holds a
+// column); `slot_col` names the column at a segment's first lane.  A column's degree is not stored:
+// it is the number of lanes of its segment that hold an edge, so appending a row to the graph
+// (scaldpc_bp_append_rows) writes ONE slot word per new edge as long as the segment has a free lane.
+// A fresh decoder packs columns in degree order with cap = max(degree, 1) -- no lane wasted; one
+// that grows leaves a few free lanes per column and moves a column that outgrows its segment.
 // All of a wave's messages arrive with ONE gather (a thread walking its column alone pays a
 // dependent cross-XCD load per edge: 25 us per pass), then the exclusive prefix / suffix sums
 // run over the segment with per-lane shuffles in the reference's sequential order:
@@ -844,9 +850,8 @@ __global__ __launch_bounds__(256) void k_el_check(const int *__restrict__ row_pt
 // posterior and hard decision out); the codewords of one tile word are set / cleared with
 // atomics (each launch row owns one bit).
 // grid (waves padded to a multiple of 8 over 4, nb), block 256 = 4 packed waves.
-__global__ __launch_bounds__(256) void k_el_var(const int2 *__restrict__ slots, const int2 *__restrict__ wave_info,
-                                                const int *__restrict__ cols, int nwaves,
-                                                const float *__restrict__ prior, float *emsg,
+__global__ __launch_bounds__(256) void k_el_var(const int2 *__restrict__ slots, const int *__restrict__ slot_col,
+                                                int nwaves, const float *__restrict__ prior, float *emsg,
                                                 float *__restrict__ post, u64 *__restrict__ hard,
                                                 u64 *done, int skip_done, long E, int write_out,
                                                 const int *__restrict__ unsat_prev, int it_prev, u64 *conv,
@@ -876,18 +881,23 @@ __global__ __launch_bounds__(256) void k_el_var(const int2 *__restrict__ slots, 
         if (w == 0 && lane == 0 && !frozen) atomicAdd(remaining_prev, 1);
     }
     const int2 sl = slots[(size_t)w * 64 + lane];
-    const int e = sl.x, start = sl.y & 63, pos = (sl.y >> 6) & 127, deg = (sl.y >> 13) & 127;
-    const bool head = ((sl.y >> 20) & 1) && pos == 0;  // first lane of a column's segment
-    const int2 wi = wave_info[w];
-    const int dmax = rfl(wi.x);
+    const int e = sl.x, start = sl.y & 63, pos = (sl.y >> 6) & 63, cap = ((sl.y >> 12) & 63) + 1;
+    const bool live = (sl.y >> 18) & 1;
+    const bool head = live && pos == 0;  // first lane of a column's segment
+    // degree = lanes of the segment that hold an edge; the wave's loop bound = its largest degree
+    const u64 has = __ballot(e >= 0);
+    const u64 segmask = (cap == 64 ? ~0ull : ((1ull << cap) - 1ull)) << start;
+    const int deg = live ? __popcll(has & segmask) : 0;
+    int dmax = deg;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) dmax = max(dmax, __shfl_xor(dmax, off));
+    dmax = rfl(dmax);
     float *mt = emsg + (size_t)c * E;
     const float mk = e >= 0 ? mt[e] : 0.0f;
-    // the column id of a segment = (number of heads before it)-th column of this wave
-    const u64 heads = __ballot(head);
     int v = 0;
     float pr = 0.0f;
     if (head) {
-        v = cols[rfl(wi.y) + __popcll(heads & ((1ull << lane) - 1))];
+        v = slot_col[(size_t)w * 64 + lane];
         pr = prior[v];
     }
     pr = __shfl(pr, start);
@@ -909,6 +919,13 @@ __global__ __launch_bounds__(256) void k_el_var(const int2 *__restrict__ slots, 
             atomicAnd(hard + v, ~(1ull << c));
         if (post) post[(size_t)v * TW + c] = tot;
     }
+}
+
+// dst[idx] = val for a list of {idx, val} pairs (table updates of scaldpc_bp_append_rows).  grid ceil(n/256).
+__global__ __launch_bounds__(256) void k_apply_pairs(int *__restrict__ dst, const int2 *__restrict__ pairs, int n)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) dst[pairs[i].x] = pairs[i].y;
 }
 
 // ---------------------------------------------------------------------------

@@ -250,6 +250,9 @@ class HqcCheckAccumulator:
         self.decoder_stats = []
         self.num_oracle_calls = 0
         self._previous_decoding = 0
+        self._bpd = None  # the decoder kept alive between decodes (rows are appended to it)
+        self._bpd_R = 0  # checks it already holds
+        self._bpd_omega = None
 
     def __len__(self):
         return self._R
@@ -278,18 +281,42 @@ class HqcCheckAccumulator:
         # each row: its W sorted circulant positions (< N), then its identity column N + i -- CSR as it stands
         return TannerGraph.from_csr(R, self.N + R, np.arange(R + 1, dtype=np.int64) * (W + 1), self._cols[:R].reshape(-1))
 
+    def _decoder(self, omega):
+        """The decoder for the checks accumulated so far.  The reference builds a new one from the dense
+        matrix on every decode (hqc.py:680,694); here ONE decoder lives through the attack and the checks
+        added since the last decode are APPENDED to it (`append_rows`: CSR tail, their identity columns and
+        priors) -- same results as a fresh decoder, without re-validating, re-sorting and re-uploading the
+        rows it already holds.  Decoder classes without `append_rows` (test doubles) are rebuilt."""
+        R, W = self._R, self.k.size
+        cls = self.bp_decoder or _default_bp()
+        if self._bpd is not None and (not hasattr(self._bpd, "append_rows") or self._bpd_omega != omega or R < self._bpd_R):
+            self.close()
+        if self._bpd is None:
+            probs = np.concatenate([np.full(self.N, omega / self.N), 1 - self._cert[:R]])
+            with np.errstate(divide="ignore"):
+                self._bpd = cls(self.graph(), max_iter=self.max_iter, bp_method="product_sum", channel_probs=probs)
+            self._bpd_omega = omega
+        elif R > self._bpd_R:
+            k = R - self._bpd_R
+            with np.errstate(divide="ignore"):
+                self._bpd.append_rows(np.arange(k + 1, dtype=np.int32) * (W + 1), self._cols[self._bpd_R : R].reshape(-1),
+                                      self.N + R, 1 - self._cert[self._bpd_R : R])
+        self._bpd_R = R
+        return self._bpd
+
+    def close(self):
+        if self._bpd is not None and hasattr(self._bpd, "close"):
+            self._bpd.close()
+        self._bpd = None
+        self._bpd_R = 0
+
     def decode(self, y_sparse):
         """hqc.py:661-759 on the accumulated checks; appends the stats row (hqc.py:750-758)."""
         R = self._R
-        H = self.graph()
-        probs = np.concatenate([np.full(self.N, len(y_sparse) / self.N), 1 - self._cert[:R]])
-        with np.errstate(divide="ignore"):
-            bpd = (self.bp_decoder or _default_bp())(H, max_iter=self.max_iter, bp_method="product_sum", channel_probs=probs)
+        bpd = self._decoder(len(y_sparse))
         cvals = self._vals[:R].copy()
         msg = np.concatenate([np.zeros(self.N, dtype=np.uint8), cvals])
         decoded = bpd.decode_batch(msg[None, :], early_exit=True, input_vector_type="received_vector")["bits"][0]
-        if hasattr(bpd, "close"):
-            bpd.close()
         success, stats = hqc_stats(self.N, decoded, cvals, y_sparse)
         row = {"checks": R, "oracle_calls": self.num_oracle_calls}
         row.update({k: v for k, v in stats.items() if k != "checks"})

@@ -263,7 +263,7 @@ def test_bench_configuration_against_oracle(oracle, method, decode_path):
     compare(sub, ref, method)
     if method == "product_sum":
         assert check_reference_form(oracle, sub, H, probs, msg[pick], 1, iters, False, threads=16) > 0.5
-    ok = (got["bits"][:, :N] == ys).all(axis=1)
+    ok = trials.success(got["bits"], ys, N)
     assert 0.7 < ok.mean() < 0.95  # the bench line's decode_success_rate (0.81 at eps = 0.05)
 
 
