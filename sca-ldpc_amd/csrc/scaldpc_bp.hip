@@ -71,6 +71,7 @@ struct Knobs {
     int compact_after = -1;   // -1 = default (4); 0 = no compact pass
     int minsum_loop = 0;      // loop form of the min-sum check kernel (A/B knob)
     int var_order = 0;        // k_var launch order inside a degree: 0 = ascending column id, 1 = by first edge id
+    int var_form = 0;         // k_var: 0 = ids fetched edge by edge, 1 = all ids up front + SGPR-base gathers (A/B)
 };
 
 struct scaldpc_bp {
@@ -195,6 +196,7 @@ bool set_knob(Knobs &k, const char *key, const char *val)
     else if (!strcmp(key, "compact_after")) k.compact_after = (int)x;
     else if (!strcmp(key, "minsum_loop")) k.minsum_loop = (int)x != 0;
     else if (!strcmp(key, "var_order")) k.var_order = (int)x;
+    else if (!strcmp(key, "var_form")) k.var_form = (int)x;
     else return false;
     return true;
 }
@@ -204,7 +206,7 @@ void knobs_from_env(Knobs &k)
     static const char *const names[][2] = {{"SCALDPC_PATH", "path"}, {"SCALDPC_SPLIT", "split"},
                                            {"SCALDPC_GROUP_MB", "group_mb"}, {"SCALDPC_EL_MAX", "el_max"},
                                            {"SCALDPC_EL_FUSE", "el_fuse"}, {"SCALDPC_COMPACT_AFTER", "compact_after"},
-                                           {"SCALDPC_VAR_ORDER", "var_order"}};
+                                           {"SCALDPC_VAR_ORDER", "var_order"}, {"SCALDPC_VAR_FORM", "var_form"}};
     for (auto &nm : names)
         if (const char *e = getenv(nm[0])) (void)set_knob(k, nm[1], e);
     if (getenv("SCALDPC_MINSUM_LOOP")) k.minsum_loop = 1;  // presence switches it on, as before
@@ -352,7 +354,7 @@ int ensure_tile_tables(scaldpc_bp *h)
         total += (cnt + 63) / 64 * 64;
         return off;
     };
-    const size_t o_var_meta = reserve((size_t)4 * VAR_REC * hv.bk.blk[hv.bk.nb] + 4), o_csc_list = reserve((size_t)h->E + 1);
+    const size_t o_var_meta = reserve((size_t)4 * VAR_REC * hv.bk.blk[hv.bk.nb] + 4), o_csc_list = reserve((size_t)h->E + 1 + 64);
     const size_t o_row_list = reserve((size_t)16 * hr.bk.blk[hr.bk.nb] + 4);
     int *host = stage_buffer(total);
     if (!host) return fail(SCALDPC_ENOMEM, "out of host memory");
@@ -450,18 +452,23 @@ int el_alloc_segment(scaldpc_bp *h, int cap)
     return slot;
 }
 
-// device copy of the mirrors: [slots: 2 ints per lane][slot_col: 1 int per lane] for el_cap_bins bins
+// device copy of the mirrors: [slots: 2 ints per lane][slot_col: 1 int per lane] for el_cap_bins bins.
+// EVERY lane of the table is initialised (bins not yet in use hold dead lanes): an append that opens a
+// new bin only sends the words it changes, and a launch covers whole bins.
 int el_upload(scaldpc_bp *h)
 {
     dev_free(h->d_el_tab);
     h->el_cap_bins = h->incremental ? h->el_waves + h->el_waves / 2 + 64 : h->el_waves;
-    const size_t lanes = (size_t)64 * h->el_cap_bins, used = (size_t)64 * h->el_waves;
+    const size_t lanes = (size_t)64 * h->el_cap_bins, old = h->h_el_col.size();
+    h->h_el_slots.resize(2 * lanes, 0);
+    h->h_el_col.resize(lanes, 0);
+    for (size_t i = old; i < lanes; i++) h->h_el_slots[2 * i] = -1;
     SC_TRY(dev_alloc(&h->d_el_tab, 3 * lanes));
     h->d_el_slots = h->d_el_tab;
     h->d_el_slot_col = h->d_el_tab + el_col_off(h);
-    if (used) {
-        SC_HIP(hipMemcpy(h->d_el_slots, h->h_el_slots.data(), 2 * used * sizeof(int), hipMemcpyHostToDevice));
-        SC_HIP(hipMemcpy(h->d_el_slot_col, h->h_el_col.data(), used * sizeof(int), hipMemcpyHostToDevice));
+    if (lanes) {
+        SC_HIP(hipMemcpy(h->d_el_slots, h->h_el_slots.data(), 2 * lanes * sizeof(int), hipMemcpyHostToDevice));
+        SC_HIP(hipMemcpy(h->d_el_slot_col, h->h_el_col.data(), lanes * sizeof(int), hipMemcpyHostToDevice));
     }
     return 0;
 }
@@ -604,15 +611,22 @@ int launch_var(scaldpc_bp *h, int G, float *post_g, u64 *hard_g, const u64 *done
     dim3 grid(h->var_bk.blk[h->var_bk.nb], G);
     float *const msg0 = h->d_msg + (size_t)tile0 * h->E * TW;
     float *const scr0 = h->d_scratch ? h->d_scratch + (size_t)tile0 * h->E * TW : nullptr;
-#define VAR_LAUNCH(CAP)                                                                                             \
-    hipLaunchKernelGGL(k_var<CAP>, grid, dim3(256), 0, s, h->var_bk, h->d_var_meta, h->d_col_ptr, h->d_csc_list,      \
+#define VAR_LAUNCH(CAP, FORM)                                                                                       \
+    hipLaunchKernelGGL((k_var<CAP, FORM>), grid, dim3(256), 0, s, h->var_bk, h->d_var_meta, h->d_col_ptr, h->d_csc_list, \
                        h->d_prior, msg0, scr0, post_g, hard_g, done_g, skip_done, h->n, h->E, write_out)
-    if (h->max_col_deg <= 16)
-        VAR_LAUNCH(16);
+    if (h->kn.var_form == 1) {  // A/B: edge ids fetched up front as wide scalar loads, SGPR-base gathers
+        if (h->max_col_deg <= 16)
+            VAR_LAUNCH(16, 1);
+        else if (h->max_col_deg <= 32)
+            VAR_LAUNCH(32, 1);
+        else
+            VAR_LAUNCH(64, 1);
+    } else if (h->max_col_deg <= 16)
+        VAR_LAUNCH(16, 0);
     else if (h->max_col_deg <= 32)
-        VAR_LAUNCH(32);
+        VAR_LAUNCH(32, 0);
     else
-        VAR_LAUNCH(64);
+        VAR_LAUNCH(64, 0);
 #undef VAR_LAUNCH
     LAUNCH_CHECK();
     return 0;

@@ -666,6 +666,47 @@ __device__ __forceinline__ float var_col(float *mt, const int *__restrict__ ce0,
     return temp;
 }
 
+// Same column update with the edge ids fetched FIRST, all of them, as wide scalar loads (the record's
+// inline ids, then the column's list), so that the gathers issue back to back: in the form above the
+// compiler fetches one id per edge with `s_load_dword` + `s_waitcnt lgkmcnt(0)` right in front of each
+// gather (the branch on `k < d` keeps it from hoisting them), i.e. the gathers of a degree-11 column
+// leave the wave a scalar-cache round trip apart.  The message row of edge e is addressed as
+// (uniform base + e * 256) + lane * 4: the edge enters on the scalar side (SGPR base of the
+// global_load), the lane offset is the one VGPR.  Same operations, same order: identical results.
+template <int MAXD>
+__device__ __forceinline__ float var_col_s(float *tile_base, int lane, const int4 *__restrict__ rec4,
+                                           const int *__restrict__ ce1, int d, float pr)
+{
+    int eid[MAXD];
+    {
+        const int4 a = rec4[1], b = rec4[2], c = rec4[3], e = rec4[4];  // uniform address: scalar loads
+        const int in16[16] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, c.x, c.y, c.z, c.w, e.x, e.y, e.z, e.w};
+#pragma unroll
+        for (int k = 0; k < MAXD && k < VAR_INLINE; k++) eid[k] = in16[k];
+#pragma unroll
+        for (int k = VAR_INLINE; k < MAXD; k++) eid[k] = ce1[k];  // (the list is padded: reads past a column stay inside it)
+    }
+    float mm[MAXD], pp[MAXD];
+#pragma unroll
+    for (int k = 0; k < MAXD; k++)
+        if (k < d) mm[k] = (tile_base + (size_t)rfl(eid[k]) * TW)[lane];
+    float temp = pr;
+#pragma unroll
+    for (int k = 0; k < MAXD; k++)
+        if (k < d) {
+            pp[k] = temp;
+            temp += mm[k];
+        }
+    float suf = 0.0f;
+#pragma unroll
+    for (int k = MAXD - 1; k >= 0; k--)
+        if (k < d) {
+            (tile_base + (size_t)rfl(eid[k]) * TW)[lane] = pp[k] + suf;
+            suf += mm[k];
+        }
+    return temp;
+}
+
 // Any-degree fallback: prefix parked in the scratch array, second sweep re-reads c2v
 // just before overwriting it.
 __device__ __forceinline__ float var_col_generic(float *mt, float *st, const int *__restrict__ ce, int d, float pr)
@@ -691,7 +732,7 @@ __device__ __forceinline__ float var_col_generic(float *mt, float *st, const int
 // write_out: also emit hard-decision planes (merged under the done mask) and, if
 // `post` is non-null, the posterior of every not-yet-frozen codeword.
 // CAP = largest unroll bound compiled in (see k_check_tanh).
-template <int CAP>
+template <int CAP, int FORM = 0>
 __global__ __launch_bounds__(256) void k_var(Buckets bk, const int *__restrict__ list,
                                              const int *__restrict__ col_ptr, const int *__restrict__ csc_edge,
                                              const float *__restrict__ prior, float *msg, float *scratch,
@@ -716,6 +757,24 @@ __global__ __launch_bounds__(256) void k_var(Buckets bk, const int *__restrict__
     const int *ce = csc_edge + cb, *ce0 = rec + 4;
     const float pr = prior[v];
     float L = pr;
+    if constexpr (FORM == 1) {
+        float *tb = msg + (size_t)tl * E * TW;
+        const int4 *r4 = (const int4 *)rec;
+        switch (rec[3]) {
+            case 1: L = var_col_s<1>(tb, lane, r4, ce, d, pr); break;
+            case 2: L = var_col_s<2>(tb, lane, r4, ce, d, pr); break;
+            case 4: L = var_col_s<4>(tb, lane, r4, ce, d, pr); break;
+            case 8: L = var_col_s<8>(tb, lane, r4, ce, d, pr); break;
+            case 16: L = var_col_s<16>(tb, lane, r4, ce, d, pr); break;
+            case 32:
+                if constexpr (CAP >= 32) L = var_col_s<32>(tb, lane, r4, ce, d, pr);
+                break;
+            case 64:
+                if constexpr (CAP >= 64) L = var_col_s<64>(tb, lane, r4, ce, d, pr);
+                break;
+            default: L = var_col_generic(mt, scratch + (size_t)tl * E * TW + lane, ce, d, pr);
+        }
+    } else
     switch (rec[3]) {
         case 1: L = var_col<1>(mt, ce0, ce, d, pr); break;
         case 2: L = var_col<2>(mt, ce0, ce, d, pr); break;

@@ -2,8 +2,10 @@
 as the drivers use it: `getattr(simulate_rs, "DecoderN450R150V3C7B1")`
 (simulate/decode.py:227-229), `DecoderN1280R512SW6` (simulate/kyber.py:396-402).
 
-Any `DecoderN{N}R{R}V{DV}C{DC}B{B}` / `DecoderN{N}R{R}SW{SW}` name resolves: sizes are
-run-time values here, not compile-time const generics.
+Any `DecoderN{N}R{R}V{DV}C{DC}B{B}` / `DecoderN{N}R{R}SW{SW}` name with check degree DC <= 8 (the
+reference registers 4 and 7, lib.rs:32-75) and symbols within int8 resolves: sizes are run-time values
+here, not compile-time const generics.  A name beyond that is an AttributeError at look-up, exactly as a
+size the reference has not registered is.
 
 `Hqc128/192/256` (liboqs KEM wrappers, simulate_rs/src/hqc.rs) are outside the decode path.
 They exist here only so that `from simulate_rs import Hqc128, Hqc192, Hqc256`

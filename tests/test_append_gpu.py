@@ -67,7 +67,7 @@ def test_hqc128_graph_grown_50_rows_at_a_time_equals_fresh_decoders():
             fresh = bp.bp_decoder(graph(r), max_iter=100, bp_method="product_sum", channel_probs=probs(r))
             a = live.decode_batch(msg(r, 1), early_exit=True, want_llr=True)
             b = fresh.decode_batch(msg(r, 1), early_exit=True, want_llr=True)
-            assert live.last_row_parallel() == 1
+            assert live.last_row_parallel() == (1 if r >= 100 else 0)  # (the first 50 rows still fit the LDS-resident decoder)
             _same(a, b, f"single decode at {r} checks")
             if i % 16 == 15 or r == R:
                 a = live.decode_batch(msg(r, 70), early_exit=True, want_llr=True)
