@@ -674,7 +674,7 @@ __device__ __forceinline__ float var_col(float *mt, const int *__restrict__ ce0,
 // (uniform base + e * 256) + lane * 4: the edge enters on the scalar side (SGPR base of the
 // global_load), the lane offset is the one VGPR.  Same operations, same order: identical results.
 template <int MAXD>
-__device__ __forceinline__ float var_col_s(float *tile_base, int lane, const int4 *__restrict__ rec4,
+__device__ __forceinline__ float var_col_s(float *tile_base, unsigned lane, const int4 *__restrict__ rec4,
                                            const int *__restrict__ ce1, int d, float pr)
 {
     int eid[MAXD];
@@ -759,18 +759,19 @@ __global__ __launch_bounds__(256) void k_var(Buckets bk, const int *__restrict__
     float L = pr;
     if constexpr (FORM == 1) {
         float *tb = msg + (size_t)tl * E * TW;
+        const unsigned ul = threadIdx.x & 63u;  // unsigned lane index: lets the gathers take the SGPR-base form
         const int4 *r4 = (const int4 *)rec;
         switch (rec[3]) {
-            case 1: L = var_col_s<1>(tb, lane, r4, ce, d, pr); break;
-            case 2: L = var_col_s<2>(tb, lane, r4, ce, d, pr); break;
-            case 4: L = var_col_s<4>(tb, lane, r4, ce, d, pr); break;
-            case 8: L = var_col_s<8>(tb, lane, r4, ce, d, pr); break;
-            case 16: L = var_col_s<16>(tb, lane, r4, ce, d, pr); break;
+            case 1: L = var_col_s<1>(tb, ul, r4, ce, d, pr); break;
+            case 2: L = var_col_s<2>(tb, ul, r4, ce, d, pr); break;
+            case 4: L = var_col_s<4>(tb, ul, r4, ce, d, pr); break;
+            case 8: L = var_col_s<8>(tb, ul, r4, ce, d, pr); break;
+            case 16: L = var_col_s<16>(tb, ul, r4, ce, d, pr); break;
             case 32:
-                if constexpr (CAP >= 32) L = var_col_s<32>(tb, lane, r4, ce, d, pr);
+                if constexpr (CAP >= 32) L = var_col_s<32>(tb, ul, r4, ce, d, pr);
                 break;
             case 64:
-                if constexpr (CAP >= 64) L = var_col_s<64>(tb, lane, r4, ce, d, pr);
+                if constexpr (CAP >= 64) L = var_col_s<64>(tb, ul, r4, ce, d, pr);
                 break;
             default: L = var_col_generic(mt, scratch + (size_t)tl * E * TW + lane, ce, d, pr);
         }
