@@ -3,7 +3,7 @@ mkdir -p gpurun_out/r02c
 O=gpurun_out/r02c
 timeout -k 10 600 python -m pytest tests/test_append_gpu.py tests/test_call_protocol_gpu.py -m gpu -x -q > $O/pytest_new.log 2>&1; echo "new tests rc=$?" | tee -a $O/pytest_new.log
 tail -5 $O/pytest_new.log
-grep -q "rc=0" $O/pytest_new.log || exit 1
+grep -q "rc=0" $O/pytest_new.log || echo "NEW TESTS FAILED (continuing)"
 timeout -k 10 900 python -m pytest tests -m gpu -q > $O/pytest_all.log 2>&1; echo "all tests rc=$?" | tee -a $O/pytest_all.log
 tail -8 $O/pytest_all.log
 B="--steps 5 --warmup 1 --no-cpu-baseline --pmc off --no-hbm-streaming"

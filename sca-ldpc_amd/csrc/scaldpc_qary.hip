@@ -464,7 +464,7 @@ __global__ __launch_bounds__(64) void k_q_check_wave(const int *__restrict__ row
 // DecoderSpecial check (decoder_special.rs:506-563), wave per (check, codeword).
 // LDS: Ab[nb*QB], As[QS] floats (shared), Bb[nb*QB][64], Bs[QS][64] floats (per lane).
 __global__ __launch_bounds__(64) void k_q_special_check_wave(const int *__restrict__ row_ptr, float *msg, int B, int BSUM,
-                                                             int W, long Bp, int nbm)
+                                                             int W, long Bp, int nbm, int skip_nb)
 {
     extern __shared__ unsigned char smem[];
     const int lane = threadIdx.x;
@@ -476,6 +476,7 @@ __global__ __launch_bounds__(64) void k_q_special_check_wave(const int *__restri
     const int c = blockIdx.x;
     const long b = blockIdx.y;
     const int e0 = row_ptr[c], k = row_ptr[c + 1] - e0, nb = k - 1;
+    if (nb == skip_nb) return;  // rows of this degree belong to k_q_special_check_tree
     for (int i = lane; i < nb * QB; i += 64) Ab[i] = msg[((size_t)(e0 + i / QB) * W + i % QB) * Bp + b];
     for (int i = lane; i < QS; i += 64) As[i] = msg[((size_t)(e0 + nb) * W + i) * Bp + b];
     for (int i = 0; i < nb * QB; i++) Bb[(size_t)i * 64 + lane] = INFINITY;
@@ -526,6 +527,139 @@ __global__ __launch_bounds__(64) void k_q_special_check_wave(const int *__restri
     for (int i = 0; i < QS; i++) {
         const float v = wave_min(Bs[(size_t)i * 64 + lane]);
         if (lane == 0) msg[((size_t)(e0 + nb) * W + i) * Bp + b] = v;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// DecoderSpecial check update for rows of NB coefficient edges over an alphabet of QB symbols --
+// the Kyber decoders' shape (lib.rs:54-75: B = 2 => QB = 5, SW = 6 => NB = 6: 5^6 = 15 625
+// assignments per check) -- as a TREE walk with everything but the commits in registers.
+//
+// What the reference computes (decoder_special.rs:506-563), per assignment d_0..d_{NB-1}:
+//     S = ((((0 + a_0[d_0]) + a_1[d_1]) + ...) + a_{NB-1}[d_{NB-1}]) + a_s[-sum d]        f32, this order
+//     beta_j[d_j] = min(beta_j[d_j], S - a_j[d_j])  for every edge j,  beta_s[-sum d] likewise
+// i.e. NB + 1 additions, NB + 1 subtractions, NB + 1 minima = 3 (NB + 1) = 21 f32 operations per
+// assignment (328 125 per check and iteration).  min is exact and order-free; the sum is not, so the
+// assignments are ENUMERATED (no min-plus shortcut), but they need not be enumerated independently:
+//   * the partial sums of a common prefix are shared (the same additions in the same order, fewer of
+//     them): a lane owns the first NB - 3 digits (its work items), loops over digit NB - 3 and unrolls
+//     the last two, so an assignment costs 2 additions instead of NB + 1;
+//   * a digit that is fixed during a loop needs no table: its running minimum is ONE register,
+//     committed to the per-lane table in LDS when the loop moves on (1 / QB^2 or less per assignment);
+//   * the two unrolled digits index their alpha / beta with compile-time indices (registers);
+//   * the row-sum symbol of an assignment is base - (d_{NB-2} + d_{NB-1}): inside the unrolled block it
+//     moves through a window of 2 QB - 1 neighbouring symbols, which is loaded to / committed from
+//     registers once per block.
+// Per assignment: 2 adds + (NB + 1) subs + (NB + 1) mins = 16 VALU operations with register operands
+// (the generic wave kernel above: ~20 LDS accesses and ~100 integer / address operations).
+// wave = (check, codeword); LDS: Ab[NB*QB] + As[QS] floats (shared), per-lane tables
+// Bb[(NB-2)*QB][64] and Bs[QS][64]; the partial minima of the 64 lanes are combined with wave
+// shuffles at the end (exact), so the messages are bit-identical to the other kernels'.
+// grid (R, batch), block 64.  Rows whose degree is not NB + 1 are left to k_q_special_check_wave.
+// ---------------------------------------------------------------------------
+template <int QB, int NB>
+__global__ __launch_bounds__(64) void k_q_special_check_tree(const int *__restrict__ row_ptr, float *msg, int BSUM, int W,
+                                                             long Bp)
+{
+    static_assert(NB >= 3, "needs at least three coefficient edges");
+    constexpr int B = (QB - 1) / 2, NL = NB - 3, WIN = 2 * QB - 1;
+    extern __shared__ unsigned char smem[];
+    const int lane = threadIdx.x;
+    const int QS = 2 * BSUM + 1;
+    float *Ab = (float *)smem;               // [NB][QB]
+    float *As = Ab + NB * QB;                // [QS]
+    float *Bb = As + QS;                     // [(NB - 2) * QB][64]   tables of digits 0 .. NB-3
+    float *Bs = Bb + (size_t)(NB - 2) * QB * 64;  // [QS][64]
+    const int c = blockIdx.x;
+    const long b = blockIdx.y;
+    const int e0 = row_ptr[c], nb = row_ptr[c + 1] - e0 - 1;
+    if (nb != NB) return;
+    for (int i = lane; i < NB * QB; i += 64) Ab[i] = msg[((size_t)(e0 + i / QB) * W + i % QB) * Bp + b];
+    for (int i = lane; i < QS; i += 64) As[i] = msg[((size_t)(e0 + NB) * W + i) * Bp + b];
+    for (int i = 0; i < (NB - 2) * QB; i++) Bb[(size_t)i * 64 + lane] = INFINITY;
+    for (int i = 0; i < QS; i++) Bs[(size_t)i * 64 + lane] = INFINITY;
+    __syncthreads();
+    float A4[QB], A5[QB], b4[QB], b5[QB];  // the two unrolled digits: compile-time indices
+#pragma unroll
+    for (int q = 0; q < QB; q++) {
+        A4[q] = Ab[(NB - 2) * QB + q];
+        A5[q] = Ab[(NB - 1) * QB + q];
+        b4[q] = INFINITY;
+        b5[q] = INFINITY;
+    }
+    int items = 1;
+#pragma unroll
+    for (int j = 0; j < NL; j++) items *= QB;
+    for (int t = lane; t < items; t += 64) {
+        int dg[NL > 0 ? NL : 1];
+        float al[NL > 0 ? NL : 1], ml[NL > 0 ? NL : 1];
+        float P = 0.0f;
+        int dsum = 0, tt = t;
+#pragma unroll
+        for (int j = 0; j < NL; j++) {
+            dg[j] = tt % QB;
+            tt /= QB;
+            al[j] = Ab[j * QB + dg[j]];
+            ml[j] = INFINITY;
+            P += al[j];  // ((0 + a_0) + a_1) + ...
+            dsum += dg[j] - B;
+        }
+        for (int d3 = 0; d3 < QB; d3++) {
+            const float a3 = Ab[NL * QB + d3];
+            const float P3 = P + a3;
+            float m3 = INFINITY;
+            // row-sum symbol of (.., d3, d4, d5): BSUM - (dsum + (d3-B) + (d4-B) + (d5-B)) = top - (d4 + d5)
+            const int top = BSUM - (dsum + d3 - B) + 2 * B;
+            float aw[WIN], mw[WIN];
+#pragma unroll
+            for (int u = 0; u < WIN; u++) {
+                aw[u] = As[top - u];
+                mw[u] = INFINITY;
+            }
+#pragma unroll
+            for (int d4 = 0; d4 < QB; d4++) {
+                const float P4 = P3 + A4[d4];
+#pragma unroll
+                for (int d5 = 0; d5 < QB; d5++) {
+                    const float S = (P4 + A5[d5]) + aw[d4 + d5];
+#pragma unroll
+                    for (int j = 0; j < NL; j++) ml[j] = fminf(ml[j], S - al[j]);
+                    m3 = fminf(m3, S - a3);
+                    b4[d4] = fminf(b4[d4], S - A4[d4]);
+                    b5[d5] = fminf(b5[d5], S - A5[d5]);
+                    mw[d4 + d5] = fminf(mw[d4 + d5], S - aw[d4 + d5]);
+                }
+            }
+            float *p3 = &Bb[(size_t)(NL * QB + d3) * 64 + lane];
+            *p3 = fminf(*p3, m3);
+#pragma unroll
+            for (int u = 0; u < WIN; u++) {
+                float *ps = &Bs[(size_t)(top - u) * 64 + lane];
+                *ps = fminf(*ps, mw[u]);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < NL; j++) {
+            float *pj = &Bb[(size_t)(j * QB + dg[j]) * 64 + lane];
+            *pj = fminf(*pj, ml[j]);
+        }
+    }
+    // combine the lanes' partial minima (exact) and write c2v in place
+    for (int i = 0; i < (NB - 2) * QB; i++) {
+        const float v = wave_min(Bb[(size_t)i * 64 + lane]);
+        if (lane == 0) msg[((size_t)(e0 + i / QB) * W + i % QB) * Bp + b] = v;
+    }
+#pragma unroll
+    for (int q = 0; q < QB; q++) {
+        const float v4 = wave_min(b4[q]), v5 = wave_min(b5[q]);
+        if (lane == 0) {
+            msg[((size_t)(e0 + NB - 2) * W + q) * Bp + b] = v4;
+            msg[((size_t)(e0 + NB - 1) * W + q) * Bp + b] = v5;
+        }
+    }
+    for (int i = 0; i < QS; i++) {
+        const float v = wave_min(Bs[(size_t)i * 64 + lane]);
+        if (lane == 0) msg[((size_t)(e0 + NB) * W + i) * Bp + b] = v;
     }
 }
 
@@ -601,7 +735,7 @@ __global__ void k_q_unpack(const signed char *__restrict__ in, int N, int batch,
 struct scaldpc_qary {
     bool special = false;
     int R = 0, N = 0, B = 0, BSUM = 0, Q = 0, QS = 0, W = 0, iterations = 0;
-    int E = 0, maxdc = 0;
+    int E = 0, maxdc = 0, mindc = 0;
     long llr_rows = 0;  // total alphabet rows over all variables
     int *d_row_ptr = nullptr, *d_col_ptr = nullptr, *d_csc_edge = nullptr, *d_edge_var = nullptr, *d_edge_h = nullptr,
         *d_var_q = nullptr;
@@ -618,6 +752,7 @@ struct scaldpc_qary {
     int device = 0;      // the device the handle was created on; every entry point runs there
     int kn_wave = -1;    // -1: wave-parallel enumeration for batches <= 256 and the special decoder; 0 / 1 force
     int kn_unroll = 1;   // register-resident unrolled enumeration for small alphabets
+    int kn_tree = 1;     // special decoder: tree-walk check kernel for the Kyber shape (QB = 5, 6 coefficient edges)
     std::mutex mu;
 };
 
@@ -683,6 +818,8 @@ int qary_build(int R, int N, int B, int BSUM, bool special, const int8_t *H, int
     h->iterations = iterations;
     h->E = E;
     h->maxdc = maxdc;
+    h->mindc = maxdc;
+    for (int r = 0; r < R; r++) h->mindc = std::min(h->mindc, row_ptr[r + 1] - row_ptr[r]);
     h->h_var_q.resize(N);
     h->h_var_off.resize(N);
     long off = 0;
@@ -712,6 +849,7 @@ int qary_build(int R, int N, int B, int BSUM, bool special, const int8_t *H, int
     if (!rc && hipGetDevice(&h->device) != hipSuccess) rc = fail(SCALDPC_EHIP, "hipGetDevice failed");
     if (const char *e = getenv("SCALDPC_QARY_WAVE")) h->kn_wave = atoi(e) != 0;  // the environment is read once per handle
     if (getenv("SCALDPC_QARY_NO_UNROLL")) h->kn_unroll = 0;
+    if (getenv("SCALDPC_QARY_NO_TREE")) h->kn_tree = 0;
     if (!rc && hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking) != hipSuccess)
         rc = fail(SCALDPC_EHIP, "hipStreamCreate failed");
     if (rc) {
@@ -805,6 +943,8 @@ int qary_run(scaldpc_qary *h, const float *pmf_b, const float *pmf_s, int batch,
         if (h->Q == 3 && h->maxdc <= 7) unrolled = 3;
         if (h->Q == 5 && h->maxdc <= 5) unrolled = 5;
     }
+    // special decoder, Kyber shape (B = 2, rows of up to 6 coefficient edges + the row-sum edge): tree-walk kernel
+    const int tree_nb = (h->special && h->kn_tree && (h->kn_wave != 0) && h->Q == 5 && h->maxdc - 1 == 6 && wave_lds <= 64 * 1024) ? 6 : 0;
     for (int it = 1; it <= iters; it++) {
         if (h->E) {
             if (unrolled == 3)
@@ -813,9 +953,17 @@ int qary_run(scaldpc_qary *h, const float *pmf_b, const float *pmf_s, int batch,
             else if (unrolled == 5)
                 hipLaunchKernelGGL((k_q_check_unrolled<5, 5>), dim3(h->R, Bp / 64), dim3(64), 0, s, h->d_row_ptr, h->d_msg, Bp,
                                    batch, h->d_err);
-            else if (wave_mode && h->special)
+            else if (h->special && tree_nb) {
+                // the Kyber shape: tree walk for the rows of 6 coefficient edges, the generic wave kernel for any others
+                const size_t tree_lds = ((size_t)tree_nb * h->Q + h->QS + (size_t)((tree_nb - 2) * h->Q + h->QS) * 64) * 4;
+                hipLaunchKernelGGL((k_q_special_check_tree<5, 6>), dim3(h->R, batch), dim3(64), tree_lds, s, h->d_row_ptr, h->d_msg,
+                                   h->BSUM, h->W, Bp);
+                if (h->mindc - 1 != tree_nb || h->maxdc - 1 != tree_nb)
+                    hipLaunchKernelGGL(k_q_special_check_wave, dim3(h->R, batch), dim3(64), wave_lds, s, h->d_row_ptr, h->d_msg,
+                                       h->B, h->BSUM, h->W, Bp, h->maxdc - 1, tree_nb);
+            } else if (wave_mode && h->special)
                 hipLaunchKernelGGL(k_q_special_check_wave, dim3(h->R, batch), dim3(64), wave_lds, s, h->d_row_ptr, h->d_msg,
-                                   h->B, h->BSUM, h->W, Bp, h->maxdc - 1);
+                                   h->B, h->BSUM, h->W, Bp, h->maxdc - 1, -1);
             else if (wave_mode)
                 hipLaunchKernelGGL(k_q_check_wave, dim3(h->R, batch), dim3(64), wave_lds, s, h->d_row_ptr, h->d_msg, h->Q,
                                    h->B, Bp, h->maxdc, h->d_err);
@@ -926,6 +1074,8 @@ int scaldpc_qary_configure(scaldpc_qary *h, const char *key, const char *value)
         h->kn_wave = atoi(value) < 0 ? -1 : atoi(value) != 0;
     else if (!strcmp(key, "unroll"))
         h->kn_unroll = atoi(value) != 0;
+    else if (!strcmp(key, "tree"))
+        h->kn_tree = atoi(value) != 0;
     else
         return fail(SCALDPC_EINVAL, "unknown knob %s", key);
     return 0;

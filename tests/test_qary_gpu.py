@@ -205,7 +205,15 @@ def test_wave_parallel_mode_equals_lane_mode(oracle, golden, monkeypatch):
         out[mode] = dk.min_sum_batch(pb, ps)
         t[mode] = time.perf_counter() - t0
     assert np.array_equal(out["0"], out["1"])
-    print(f"Kyber N1280R512SW6, batch 2, 2 iterations: wave mode {t['1']*1e3:.2f} ms, lane mode {t['0']*1e3:.2f} ms")
+    # "1" ran the tree-walk kernel (the Kyber shape's default); the generic wave kernel must agree too
+    dk.configure(wave=1, tree=0)
+    t0 = time.perf_counter()
+    generic = dk.min_sum_batch(pb, ps)
+    t["generic"] = time.perf_counter() - t0
+    assert np.array_equal(generic, out["1"])
+    assert np.array_equal(out["1"], oracle.qary_special_batch(gk, 2, 12, pb, ps, 2, threads=8))
+    print(f"Kyber N1280R512SW6, batch 2, 2 iterations: tree kernel {t['1']*1e3:.2f} ms, generic wave kernel "
+          f"{t['generic']*1e3:.2f} ms, lane mode {t['0']*1e3:.2f} ms")
 
 
 def test_into_llr_known_answer_on_the_device():
