@@ -174,7 +174,9 @@ int scaldpc_bp_last_stats(scaldpc_bp *h, int64_t *out);
  *   "compact_after" iteration from which stragglers may be handed to a compact pass (default 4, 0 = never)
  *   "minsum_loop"   1 = loop form of the min-sum check kernel (A/B)
  *   "var_order"     order of the columns of one degree in a variable-node launch: 0 ascending column,
- *                   1 by first edge id (default).  Results never depend on any of these. */
+ *                   1 by first edge id (default)
+ *   "var_form"      variable-node kernel: 1 = a wave fetches all its edge ids up front as wide scalar loads
+ *                   (default), 0 = one scalar load per edge.  Results never depend on any of these. */
 int scaldpc_bp_configure(scaldpc_bp *h, const char *key, const char *value);
 /* Where a handle lives, out[4]: the device it was created on; the device (hipPointerGetAttributes)
  * of its graph allocation, of its message workspace and of its state planes (-1 = not allocated yet).
