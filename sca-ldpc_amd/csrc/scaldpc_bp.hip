@@ -148,6 +148,9 @@ struct scaldpc_bp {
     float *d_prior_buf = nullptr;
     size_t cap_rows = 0, cap_edges = 0, cap_cols = 0;
     int ws_m = 0, ws_n = 0;  // what the workspace planes are sized for
+    std::vector<unsigned> el_stamp;        // per word of h_el_slots: append call that last changed it (dirty-list dedup)
+    std::vector<int> el_dirty_slot, el_dirty_col;
+    unsigned el_epoch = 0;
     int *d_pairs = nullptr;  // staging of table updates
     int *h_pairs = nullptr;  // pinned
     size_t cap_pairs = 0;
@@ -1323,6 +1326,7 @@ int scaldpc_bp_append_rows(scaldpc_bp *h, int32_t nrows, const int32_t *row_ptr,
     }
     if (nrows == 0 && new_n == h->n) return 0;
     if (h->async_used) SC_HIP(hipDeviceSynchronize());  // the tables below may still be read by work in flight
+    TMARK("app:start");
     SC_TRY(make_incremental(h));
     hipStream_t s = h->own_stream;
     const int m0 = h->m, n0 = h->n;
@@ -1341,17 +1345,23 @@ int scaldpc_bp_append_rows(scaldpc_bp *h, int32_t nrows, const int32_t *row_ptr,
     h->hg_cdeg.resize(new_n, 0);
     for (int r = 0; r < nrows; r++) h->max_row_deg = std::max(h->max_row_deg, row_ptr[r + 1] - row_ptr[r]);
 
+    TMARK("app:mirror");
     // ---- row-parallel tables, in place: one slot word per new edge while its column has a free lane
     const bool had_tables = h->d_el_tab != nullptr;
-    std::vector<int> dirty_slot, dirty_col;  // indices into h_el_slots / h_el_col that changed
+    std::vector<int> &dirty_slot = h->el_dirty_slot, &dirty_col = h->el_dirty_col;  // words of h_el_slots / h_el_col that changed
+    dirty_slot.clear();
+    dirty_col.clear();
+    const unsigned epoch = ++h->el_epoch;
     bool el_alive = had_tables;
     if (had_tables) {
         h->seg_slot.resize(new_n, -1);
         h->seg_cap.resize(new_n, 0);
     }
-    auto set_slot = [&](size_t i, int v) {
-        if (h->h_el_slots[i] != v) {
-            h->h_el_slots[i] = v;
+    auto set_slot = [&](size_t i, int v) {  // each changed word is listed once, whatever happens to it later in this call
+        h->h_el_slots[i] = v;
+        if (h->el_stamp.size() <= i) h->el_stamp.resize(h->h_el_slots.size() + 4096, 0u);
+        if (h->el_stamp[i] != epoch) {
+            h->el_stamp[i] = epoch;
             dirty_slot.push_back((int)i);
         }
     };
@@ -1361,10 +1371,8 @@ int scaldpc_bp_append_rows(scaldpc_bp *h, int32_t nrows, const int32_t *row_ptr,
             set_slot(2 * (size_t)(s0 + k), k < d ? edges[k] : -1);
             set_slot(2 * (size_t)(s0 + k) + 1, el_tag(start, k, cap, true));
         }
-        if (h->h_el_col[s0] != c) {
-            h->h_el_col[s0] = c;
-            dirty_col.push_back(s0);
-        }
+        h->h_el_col[s0] = c;
+        dirty_col.push_back(s0);  // (a segment start is handed out once: no duplicates)
         h->seg_slot[c] = s0;
         h->seg_cap[c] = (unsigned char)cap;
     };
@@ -1384,14 +1392,12 @@ int scaldpc_bp_append_rows(scaldpc_bp *h, int32_t nrows, const int32_t *row_ptr,
         } else if (d_old < h->seg_cap[c]) {
             set_slot(2 * (size_t)(h->seg_slot[c] + d_old), e);
         } else {  // the segment is full: the column moves to a larger one, its old lanes go dead
-            const int s_old = h->seg_slot[c], cap_old = h->seg_cap[c];
+            const int s_old = h->seg_slot[c];
             for (int k = 0; k < d_old; k++) edges_tmp[k] = h->h_el_slots[2 * (size_t)(s_old + k)];
             edges_tmp[d_old] = e;
-            for (int k = 0; k < cap_old; k++) {
-                set_slot(2 * (size_t)(s_old + k), -1);
-                set_slot(2 * (size_t)(s_old + k) + 1, 0);
-            }
-            new_segment(c, std::min(64, d_old + 1 + el_slack(h, c, d_old + 1)), edges_tmp, d_old + 1);
+            for (int k = 0; k < d_old; k++) set_slot(2 * (size_t)(s_old + k), -1);  // (the free lanes hold -1 already)
+            set_slot(2 * (size_t)s_old + 1, 0);  // no head, no column: the other lanes of the old segment just idle
+            new_segment(c, std::min(64, d_old + 1 + std::max(el_slack(h, c, d_old + 1), (d_old + 1) / 2)), edges_tmp, d_old + 1);
         }
     }
     if (el_alive)
@@ -1408,11 +1414,8 @@ int scaldpc_bp_append_rows(scaldpc_bp *h, int32_t nrows, const int32_t *row_ptr,
         el_alive = false;
     }
 
+    TMARK("app:tables");
     // ---- device: CSR tails, table words -----------------------------------------------------------
-    std::sort(dirty_slot.begin(), dirty_slot.end());
-    dirty_slot.erase(std::unique(dirty_slot.begin(), dirty_slot.end()), dirty_slot.end());
-    std::sort(dirty_col.begin(), dirty_col.end());
-    dirty_col.erase(std::unique(dirty_col.begin(), dirty_col.end()), dirty_col.end());
     const bool reupload = el_alive && h->el_waves > h->el_cap_bins;  // the bins outgrew the device table
     const size_t npairs = (el_alive && !reupload) ? dirty_slot.size() + dirty_col.size() : 0;
     const size_t stage_ints = (size_t)nrows + add + 2 * npairs;
@@ -1453,6 +1456,7 @@ int scaldpc_bp_append_rows(scaldpc_bp *h, int32_t nrows, const int32_t *row_ptr,
         LAUNCH_CHECK();
     }
     SC_HIP(hipStreamSynchronize(s));
+    TMARK("app:device");
 
     // ---- what was sized or derived for the old graph ------------------------------------------------
     h->full_stale = true;  // CSC, degree buckets, identity block, tile tables: rebuilt when the tile / LDS kernels are next needed
@@ -1469,6 +1473,7 @@ int scaldpc_bp_append_rows(scaldpc_bp *h, int32_t nrows, const int32_t *row_ptr,
         L.cap_post = 0;
     }
     h->last_group = 0;
+    TMARK("app:tail");
     return 0;
 }
 
