@@ -23,7 +23,7 @@ bp = importlib.import_module("sca-ldpc_amd.bp")
 def main():
     rows = json.load(open(os.path.join(ROOT, "tests", "golden", "hqc_first_rows.json")))
     N, omega, eps = 17669, 66, 0.05
-    Rmax = 4400
+    Rmax = 6000
     _, Hin, _ = S.codes.hqc_bench_graph("hqc128", rows["N17669_W50_s0"], R=Rmax)
     rng = np.random.RandomState(1)
     y = np.zeros((1, N), dtype=np.uint8)
@@ -43,19 +43,21 @@ def main():
 
     for step in (50, 100):
         R0 = 4000
-        sizes = list(range(R0, Rmax + 1, step))
+        sizes = list(range(R0, Rmax + 1, step))  # 20 / 40 steps: medians below
         # rebuild per decode
         graphs = {r: graph(r) for r in sizes}
         pr = {r: probs(r) for r in sizes}
         ms = {r: msg(r) for r in sizes}
         outs_a = []
         bp.bp_decoder(graphs[R0], max_iter=100, bp_method="product_sum", channel_probs=pr[R0]).close()  # warm the block cache
-        t0 = time.perf_counter()
+        tr = []
         for r in sizes[1:]:
+            t0 = time.perf_counter()
             d = bp.bp_decoder(graphs[r], max_iter=100, bp_method="product_sum", channel_probs=pr[r])
             outs_a.append(d.decode_batch(ms[r], early_exit=True))
             d.close()
-        t_rebuild = (time.perf_counter() - t0) / (len(sizes) - 1)
+            tr.append(time.perf_counter() - t0)
+        t_rebuild = float(np.median(tr))
         # append
         live = bp.bp_decoder(graphs[R0], max_iter=100, bp_method="product_sum", channel_probs=pr[R0])
         live.decode_batch(ms[R0], early_exit=True)
@@ -63,22 +65,22 @@ def main():
         live.append_rows(*tails[sizes[1]][:2], N + sizes[1], tails[sizes[1]][2])  # first append: CSR moves to growable buffers
         live.decode_batch(ms[sizes[1]], early_exit=True)
         outs_b = [None]
-        t0 = time.perf_counter()
-        t_app = 0.0
+        ts, tapp = [], []
         for r in sizes[2:]:
             ta = time.perf_counter()
             live.append_rows(*tails[r][:2], N + r, tails[r][2])
-            t_app += time.perf_counter() - ta
+            tb = time.perf_counter()
             outs_b.append(live.decode_batch(ms[r], early_exit=True))
-        t_append = (time.perf_counter() - t0) / (len(sizes) - 2)
-        t_app /= len(sizes) - 2
+            ts.append(time.perf_counter() - ta)
+            tapp.append(tb - ta)
+        t_append, t_app = float(np.median(ts)), float(np.median(tapp))
         t0 = time.perf_counter()
         for _ in range(20):
             live.decode_batch(ms[sizes[-1]], early_exit=True)
         t_dec = (time.perf_counter() - t0) / 20
         same = all(np.array_equal(a["bits"], b["bits"]) and np.array_equal(a["iters"], b["iters"]) for a, b in zip(outs_a[1:], outs_b[1:]))
         it = [int(a["iters"][0]) for a in outs_a]
-        print(json.dumps({"rows_per_step": step, "checks": [sizes[0], sizes[-1]], "ms_per_step_rebuild": t_rebuild * 1e3,
+        print(json.dumps({"rows_per_step": step, "checks": [sizes[0], sizes[-1]], "steps_timed": len(ts), "ms_per_step_rebuild": t_rebuild * 1e3,
                           "ms_per_step_append": t_append * 1e3, "ms_append_call_alone": t_app * 1e3,
                           "ms_decode_alone_warm": t_dec * 1e3, "iterations_per_decode": [min(it), max(it)], "outputs_identical": same}))
         live.close()

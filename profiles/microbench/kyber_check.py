@@ -26,6 +26,7 @@ PEAK_OPS = 78.6e12
 
 def main():
     iters = int(sys.argv[1]) if len(sys.argv) > 1 else 5
+    only_tree = len(sys.argv) > 2 and sys.argv[2] == "tree"  # (for a kernel profile of the default path alone)
     gens = json.load(open(os.path.join(ROOT, "tests", "golden", "generators.json")))
     g = S.TannerGraph.from_coo(gens["qary_qc_256_6_3_s0_cb2"])
     H = g.to_dense(np.int8)
@@ -36,7 +37,7 @@ def main():
         ps = rng.dirichlet(np.ones(25), size=(batch, 512)).astype(np.float32)
         res, out = {}, {}
         for name, kn in (("tree", dict(wave=-1, tree=1)), ("generic_wave", dict(wave=1, tree=0)), ("lane", dict(wave=0, tree=0))):
-            if name == "lane" and batch < 64:
+            if (name == "lane" and batch < 64) or (only_tree and name != "tree"):
                 continue  # (one codeword per lane: pointless below a wave's worth)
             dec.configure(**kn)
             dec.min_sum_batch(pb, ps)

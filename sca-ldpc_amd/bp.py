@@ -113,7 +113,15 @@ class BpDecoder:
                 f"The length of the channel probability vector must be eqaul to the block length n={self.n}."
             )
         _lib.check(self._lib.scaldpc_bp_set_channel_probs(self._h, _lib.ptr(probs)))
-        self.channel_probs = probs
+        self._probs = probs
+        self._probs_tails = []
+
+    @property
+    def channel_probs(self):
+        if self._probs_tails:
+            self._probs = np.concatenate([self._probs] + self._probs_tails)
+            self._probs_tails = []
+        return self._probs
 
     def append_rows(self, row_ptr, col_idx, new_n, channel_probs_tail):
         """The graph GROWS (the attack loop's `H = np.vstack([H, row])`, simulate/hqc.py:885-908, where the
@@ -139,7 +147,7 @@ class BpDecoder:
         self.n = new_n
         self.graph = None  # (the constructor's graph no longer describes this decoder)
         _lib.check(self._lib.scaldpc_bp_set_channel_probs_tail(self._h, old_n, new_n - old_n, _lib.ptr(tail)))
-        self.channel_probs = np.concatenate([self.channel_probs, tail])
+        self._probs_tails.append(tail)  # (`channel_probs` is put together when somebody asks: appends are on the attack loop's critical path)
 
     def _resolve_kind(self, length, input_vector_type=None):
         kind = self._vector_type if input_vector_type is None else _vector_type(input_vector_type)

@@ -148,9 +148,7 @@ struct scaldpc_bp {
     float *d_prior_buf = nullptr;
     size_t cap_rows = 0, cap_edges = 0, cap_cols = 0;
     int ws_m = 0, ws_n = 0;  // what the workspace planes are sized for
-    std::vector<unsigned> el_stamp;        // per word of h_el_slots: append call that last changed it (dirty-list dedup)
-    std::vector<int> el_dirty_slot, el_dirty_col;
-    unsigned el_epoch = 0;
+    std::vector<int> el_dirty_slot, el_dirty_col;  // words an append call changed (kept for their capacity)
     int *d_pairs = nullptr;  // staging of table updates
     int *h_pairs = nullptr;  // pinned
     size_t cap_pairs = 0;
@@ -1351,19 +1349,17 @@ int scaldpc_bp_append_rows(scaldpc_bp *h, int32_t nrows, const int32_t *row_ptr,
     std::vector<int> &dirty_slot = h->el_dirty_slot, &dirty_col = h->el_dirty_col;  // words of h_el_slots / h_el_col that changed
     dirty_slot.clear();
     dirty_col.clear();
-    const unsigned epoch = ++h->el_epoch;
     bool el_alive = had_tables;
     if (had_tables) {
         h->seg_slot.resize(new_n, -1);
         h->seg_cap.resize(new_n, 0);
     }
-    auto set_slot = [&](size_t i, int v) {  // each changed word is listed once, whatever happens to it later in this call
+    // A word may be listed more than once (filled in place, then moved with its column in the same call):
+    // the pairs sent to the device carry the mirror's FINAL value of the word, so duplicates are harmless
+    // in whatever order the scatter kernel applies them.
+    auto set_slot = [&](size_t i, int v) {
         h->h_el_slots[i] = v;
-        if (h->el_stamp.size() <= i) h->el_stamp.resize(h->h_el_slots.size() + 4096, 0u);
-        if (h->el_stamp[i] != epoch) {
-            h->el_stamp[i] = epoch;
-            dirty_slot.push_back((int)i);
-        }
+        dirty_slot.push_back((int)i);
     };
     auto new_segment = [&](int c, int cap, const int *edges, int d) {  // writes a whole segment
         const int s0 = el_alloc_segment(h, cap), start = s0 & 63;
