@@ -589,7 +589,17 @@ def cpu_baseline(H, probs, msg, iters, method, E, budget_s):
     t0 = time.perf_counter()
     pyoracle.bp_decode_batch(H, probs, msg[:sample], 1, iters, om, dtype="f32", threads=threads, early_exit=False)
     dt = time.perf_counter() - t0
+    # the arithmetic the reference's package actually runs -- float64 probability-ratio product-sum, one
+    # codeword at a time on one core (oracle method 0) -- on two codewords of the same batch
+    with np.errstate(divide="ignore", invalid="ignore"):
+        t1 = time.perf_counter()
+        pyoracle.bp_decode_batch(H, probs, msg[:2], 1, iters, "product_sum", dtype="f64", threads=1, early_exit=False)
+        one64 = (time.perf_counter() - t1) / 2
     return {
+        "reference_form_single_thread": {
+            "value": 2.0 * E * iters / one64, "unit": "directed edge-message updates/s", "cores": 1, "codewords_per_s": 1.0 / one64,
+            "what": f"float64 ratio-domain product-sum (the arithmetic of ldpc 0.1.3's bp_decoder, restated), one codeword at a "
+                    f"time on one core, {iters} fixed iterations, 2 codewords of the same batch"},
         "value": 2.0 * E * iters * sample / dt,
         "unit": "directed edge-message updates/s",
         "cores": threads,

@@ -71,7 +71,6 @@ struct Knobs {
     int compact_after = -1;   // -1 = default (4); 0 = no compact pass
     int minsum_loop = 0;      // loop form of the min-sum check kernel (A/B knob)
     int var_order = 1;        // k_var launch order inside a degree: 0 = ascending column id, 1 = by first edge id (default)
-    int check_pipe = 0;       // tanh check pass: 1 = software-pipelined grid-stride kernel on graphs of one row degree (A/B)
     int var_form = 1;         // k_var: 0 = ids fetched edge by edge, 1 = all ids up front as wide scalar loads (default)
 };
 
@@ -199,7 +198,6 @@ bool set_knob(Knobs &k, const char *key, const char *val)
     else if (!strcmp(key, "minsum_loop")) k.minsum_loop = (int)x != 0;
     else if (!strcmp(key, "var_order")) k.var_order = (int)x;
     else if (!strcmp(key, "var_form")) k.var_form = (int)x;
-    else if (!strcmp(key, "check_pipe")) k.check_pipe = (int)x;
     else return false;
     return true;
 }
@@ -209,7 +207,7 @@ void knobs_from_env(Knobs &k)
     static const char *const names[][2] = {{"SCALDPC_PATH", "path"}, {"SCALDPC_SPLIT", "split"},
                                            {"SCALDPC_GROUP_MB", "group_mb"}, {"SCALDPC_EL_MAX", "el_max"},
                                            {"SCALDPC_EL_FUSE", "el_fuse"}, {"SCALDPC_COMPACT_AFTER", "compact_after"},
-                                           {"SCALDPC_VAR_ORDER", "var_order"}, {"SCALDPC_VAR_FORM", "var_form"}, {"SCALDPC_CHECK_PIPE", "check_pipe"}};
+                                           {"SCALDPC_VAR_ORDER", "var_order"}, {"SCALDPC_VAR_FORM", "var_form"}};
     for (auto &nm : names)
         if (const char *e = getenv(nm[0])) (void)set_knob(k, nm[1], e);
     if (getenv("SCALDPC_MINSUM_LOOP")) k.minsum_loop = 1;  // presence switches it on, as before
@@ -590,12 +588,6 @@ int launch_check(scaldpc_bp *h, int method, float alpha, int G, const u64 *synd_
             if (first) MS_LAUNCH(true, true); else MS_LAUNCH(true, false);
         }
 #undef MS_LAUNCH
-    } else if (h->kn.check_pipe && !first && h->min_row_deg == h->max_row_deg && h->max_row_deg == 51) {
-        // A/B: one row degree (the HQC graphs' W + 1 = 51): software-pipelined grid-stride kernel, a launch of
-        // exactly the resident waves (2 per SIMD at this register count: 2 blocks of 4 waves per CU)
-        const int blocks = std::max(1, (h->kn.check_pipe > 1 ? h->kn.check_pipe : 512) / G);
-        hipLaunchKernelGGL((k_check_tanh_pipe<51>), dim3(blocks, G), dim3(256), 0, s, h->d_row_list, h->m, msg0, synd_g, done_g,
-                           skip_done, h->m, h->E);
     } else {
         dim3 grid(h->row_bk.blk[h->row_bk.nb], G);
 #define TANH_LAUNCH(CAP, F)                                                                                         \

@@ -389,88 +389,6 @@ __device__ __forceinline__ void check_tanh_row(float *p, unsigned sbit, const fl
     }
 }
 
-// The same row update split into its load and its compute + store halves, for the software-pipelined
-// kernel below (identical operations in identical order: identical results).
-template <int DEG>
-__device__ __forceinline__ void check_tanh_load(float (&uu)[DEG], const float *p)
-{
-#pragma unroll
-    for (int k = 0; k < DEG; k++) uu[k] = p[(size_t)k * TW];
-}
-template <int DEG>
-__device__ __forceinline__ void check_tanh_finish(float (&uu)[DEG], float *p, unsigned sbit)
-{
-    float pre[DEG];
-    unsigned acc = sbit << 31;
-    float U = 0.0f;
-#pragma unroll
-    for (int k = 0; k < DEG; k++) {
-        const unsigned xb = __float_as_uint(uu[k]);
-        acc ^= xb;
-        const float u = tanh_compl(fabsf(uu[k]));
-        uu[k] = __uint_as_float(__float_as_uint(u) | (xb & 0x80000000u));
-        pre[k] = U;
-        U = compl_step(U, u);
-    }
-    U = 0.0f;
-#pragma unroll
-    for (int k = DEG - 1; k >= 0; k--) {
-        const float Ut = compl_step(pre[k], U);
-        const float Lm = llr_from_compl(Ut);
-        const unsigned sg = (acc ^ __float_as_uint(uu[k])) & 0x80000000u;
-        U = compl_step(U, fabsf(uu[k]));
-        p[(size_t)k * TW] = __uint_as_float(__float_as_uint(Lm) ^ sg);
-    }
-}
-
-// Software-pipelined, grid-stride form of the tanh check pass for graphs whose rows all have ONE
-// degree (the HQC graphs: W + 1): a launch holds exactly as many waves as the chip keeps resident
-// and every wave walks rows wid, wid + nw, wid + 2 nw, ... of its tile with the NEXT row's loads
-// issued before the current row's arithmetic, two register buffers alternating (no copies: the
-// loop body is written out twice).  A/B knob `check_pipe`; results identical to k_check_tanh.
-// grid (resident blocks / G, G), block 256; list = the row descriptors of k_check_tanh (nd of them).
-template <int DEG>
-__global__ __launch_bounds__(256) void k_check_tanh_pipe(const int *__restrict__ list, int nd, float *msg,
-                                                         const u64 *__restrict__ synd, const u64 *__restrict__ done,
-                                                         int skip_done, int m, long E)
-{
-    const int lane = threadIdx.x & 63;
-    const int tl = blockIdx.y;
-    if (skip_done && done[tl] == ~0ull) return;
-    const int nw = (int)gridDim.x * 4;
-    int i = rfl((int)blockIdx.x * 4 + (int)(threadIdx.x >> 6));
-    if (i >= nd) return;
-    float *const mt = msg + (size_t)tl * E * TW + lane;
-    const u64 *const st = synd + (size_t)tl * m;
-    float xa[DEG], xb[DEG];
-    const int *md = list + (size_t)i * 4;
-    float *pa = mt + (size_t)md[1] * TW, *pb = pa;
-    unsigned sa = (unsigned)(st[md[0]] >> lane) & 1u, sb = 0;
-    check_tanh_load<DEG>(xa, pa);
-    for (;;) {
-        const int j = i + nw;
-        const bool hb = j < nd;
-        if (hb) {
-            md = list + (size_t)j * 4;
-            pb = mt + (size_t)md[1] * TW;
-            sb = (unsigned)(st[md[0]] >> lane) & 1u;
-            check_tanh_load<DEG>(xb, pb);
-        }
-        check_tanh_finish<DEG>(xa, pa, sa);
-        if (!hb) break;
-        i = j + nw;
-        const bool ha = i < nd;
-        if (ha) {
-            md = list + (size_t)i * 4;
-            pa = mt + (size_t)md[1] * TW;
-            sa = (unsigned)(st[md[0]] >> lane) & 1u;
-            check_tanh_load<DEG>(xa, pa);
-        }
-        check_tanh_finish<DEG>(xb, pb, sb);
-        if (!ha) break;
-    }
-}
-
 // Any-degree fallback: the forward sweep parks Upre in a scratch array (the reference
 // package parks its prefix products in the message slot), the backward sweep re-reads
 // the inputs and recomputes u before overwriting them.
