@@ -251,3 +251,40 @@ def test_into_llr_on_the_device_is_bit_identical_to_the_hosts_logf(oracle):
     # three-symbol rows as the decoders see them (decode.py:232-237 and random pmfs)
     q3 = rng.dirichlet(np.ones(3), size=1 << 18).astype(np.float32)
     assert np.array_equal(qary.into_llr(q3).view(np.uint32), oracle.qary_into_llr(q3).view(np.uint32))
+
+
+@pytest.mark.parametrize("batch", [1, 5, 70])
+def test_special_tree_kernel_with_mixed_row_degrees_and_impossible_symbols(oracle, batch):
+    """The Kyber-shape kernel (`k_q_special_check_tree<5, 6>`: rows of exactly six coefficient edges) shares a
+    decode with the generic wave kernel (rows of fewer edges): a random H = [H' | I] with rows of 3..6
+    coefficients, signed entries, pmfs with impossible symbols (+inf LLRs) on both alphabets -- against the
+    oracle, and the three kernel families against each other."""
+    rng = np.random.RandomState(100 + batch)
+    R, NB, B, SW = 14, 40, 2, 6
+    BSUM = SW * B
+    Hp = np.zeros((R, NB), dtype=np.int8)
+    for r in range(R):
+        k = 6 if r % 3 else rng.randint(3, 6)  # two thirds of the rows at full weight
+        cols = rng.choice(NB, k, replace=False)
+        Hp[r, cols] = rng.choice([-1, 1], size=k)
+    H = np.concatenate([Hp, np.eye(R, dtype=np.int8)], axis=1)
+    g = S.TannerGraph.from_dense(H)
+    pb = rng.dirichlet(np.ones(5) * 0.7, size=(batch, NB)).astype(np.float32)
+    ps = rng.dirichlet(np.ones(2 * BSUM + 1) * 0.7, size=(batch, R)).astype(np.float32)
+    zb = rng.rand(batch, NB, 5) < 0.1
+    zb[..., B] = False
+    pb[zb] = 0.0
+    pb /= pb.sum(axis=2, keepdims=True)
+    zs = rng.rand(batch, R, 2 * BSUM + 1) < 0.1
+    zs[..., BSUM - 2 : BSUM + 3] = False
+    ps[zs] = 0.0
+    ps /= ps.sum(axis=2, keepdims=True)
+    dec = qary.decoder_class(f"DecoderN{NB + R}R{R}SW{SW}")(H, 3)
+    with np.errstate(divide="ignore"):
+        ref = oracle.qary_special_batch(g, B, BSUM, pb, ps, 3, threads=8)
+        out = {}
+        for name, kn in (("tree", dict(wave=-1, tree=1)), ("generic", dict(wave=1, tree=0)), ("lane", dict(wave=0, tree=0))):
+            dec.configure(**kn)
+            out[name] = dec.min_sum_batch(pb, ps)
+    for name, o in out.items():
+        assert np.array_equal(o, ref), name
