@@ -88,6 +88,71 @@ __global__ __launch_bounds__(64) void k_unpack_state(const u64 *__restrict__ con
 }
 
 // ---------------------------------------------------------------------------
+// A call of a handful of codewords from host buffers (the attack loop's single decode(), hqc.py:708) is
+// bound by the NUMBER of launches, copies and memsets around its few iterations, so the reshaping steps
+// are fused for it: one kernel in front (pack the input bytes into planes + reset the per-tile state +
+// zero the hard-decision planes and the early-exit counters), one behind (decisions, posteriors,
+// iteration counts and flags of every codeword into ONE buffer that travels back in one copy).
+// ---------------------------------------------------------------------------
+// grid ceil(max(len, n) / 64), block 256: wave = 16 consecutive positions of the one tile.
+__global__ __launch_bounds__(256) void k_small_prepare(const uint8_t *__restrict__ in, int len, int batch,
+                                                       u64 *__restrict__ planes, int n, u64 *__restrict__ hard,
+                                                       int max_iter, u64 *__restrict__ done, u64 *__restrict__ conv,
+                                                       int *__restrict__ iters, int *__restrict__ remaining, int nrem,
+                                                       int *__restrict__ el_unsat, int nun)
+{
+    const int lane = threadIdx.x & 63;
+    const int x0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 16;
+    const uint8_t *p = in + (size_t)(lane < batch ? lane : 0) * len;
+    for (int j = 0; j < 16; j++) {
+        const int x = x0 + j;
+        if (x < len) {
+            const u64 w = __ballot(lane < batch && (p[x] & 1));
+            if (lane == 0) planes[x] = w;
+        }
+        if (x < n && lane == 0) hard[x] = 0;
+    }
+    if (blockIdx.x == 0) {
+        if (threadIdx.x < 64) {
+            iters[threadIdx.x] = max_iter;
+            const u64 pad = __ballot((int)threadIdx.x >= batch);  // padding codewords are born "done"
+            if (threadIdx.x == 0) {
+                done[0] = pad;
+                conv[0] = 0;
+            }
+        }
+        for (int i = threadIdx.x; i < nrem; i += 256) remaining[i] = 0;
+        for (int i = threadIdx.x; i < nun; i += 256) el_unsat[i] = 0;
+    }
+}
+
+// out = [bits: batch x n bytes][pad to 4][llr: batch x n floats, if post][iters: batch ints][conv: batch bytes]
+// grid ceil(n / 256), block 256: thread = variable.  One tile, batch <= 8.
+__global__ __launch_bounds__(256) void k_small_unpack(const u64 *__restrict__ hard, const u64 *__restrict__ recv,
+                                                      const float *__restrict__ post, const u64 *__restrict__ conv_bits,
+                                                      const int *__restrict__ iters, int n, int batch,
+                                                      uint8_t *__restrict__ out)
+{
+    const int v = blockIdx.x * 256 + threadIdx.x;
+    const size_t bits_bytes = ((size_t)batch * n + 3) / 4 * 4;
+    float *llr = (float *)(out + bits_bytes);
+    int *oit = (int *)(out + bits_bytes + (post ? sizeof(float) * (size_t)batch * n : 0));
+    uint8_t *ocv = (uint8_t *)(oit + batch);
+    if (v < n) {
+        u64 w = hard[v];
+        if (recv) w ^= recv[v];
+        for (int c = 0; c < batch; c++) {
+            out[(size_t)c * n + v] = (uint8_t)((w >> c) & 1);
+            if (post) llr[(size_t)c * n + v] = post[(size_t)v * TW + c];
+        }
+    }
+    if (blockIdx.x == 0 && (int)threadIdx.x < batch) {
+        oit[threadIdx.x] = iters[threadIdx.x];
+        ocv[threadIdx.x] = (uint8_t)((conv_bits[0] >> threadIdx.x) & 1);
+    }
+}
+
+// ---------------------------------------------------------------------------
 // parity of bit planes along the rows of H.
 //   CHECK = false: synd[t][r] = XOR_v bits[t][v]          (received-vector mode: s = H v)
 //   CHECK = true : unsat[t][w] = OR_r (synd[t][r] ^ XOR_v bits) over wave w's rows (convergence test H e == s)
