@@ -49,11 +49,10 @@ def main():
     # runs all max_iter = 100 iterations WITH the per-iteration convergence test
     rng = np.random.RandomState(0)
     xbad = np.concatenate([np.zeros(N, np.uint8), rng.randint(0, 2, H.m).astype(np.uint8)])
-    for label, env in (("tiles", {"SCALDPC_PATH": "stream"}), ("row-parallel, 4 launches/iteration", {"SCALDPC_EL_FUSE": "0"}),
-                       ("row-parallel, 2 launches/iteration", {})):
-        for k in ("SCALDPC_PATH", "SCALDPC_EL_FUSE"):
-            os.environ.pop(k, None)
-        os.environ.update(env)
+    # (knobs are per handle since round 2: the environment is only read when a decoder is created)
+    for label, kn in (("tiles", dict(path="stream", el_fuse=1)), ("row-parallel, 4 launches/iteration", dict(path="auto", el_fuse=0)),
+                      ("row-parallel, 2 launches/iteration", dict(path="auto", el_fuse=1))):
+        warm.configure(**kn)
         warm.decode(xbad)
         t0 = time.perf_counter()
         for _ in range(5):
@@ -61,8 +60,6 @@ def main():
         dt = (time.perf_counter() - t0) / 5
         print(json.dumps({"non_converging_decode_100_iterations": label, "ms": round(dt * 1e3, 3), "iter": int(warm.iter),
                           "converge": int(warm.converge)}), flush=True)
-    for k in ("SCALDPC_PATH", "SCALDPC_EL_FUSE"):
-        os.environ.pop(k, None)
     warm.close()
     # ... and the whole attack-loop step through the build's driver: 4000 accumulated checks,
     # sparse graph assembly in Python + new decoder + decode + statistics (hqc.py:661-759)
@@ -91,7 +88,7 @@ def main():
             x = np.ascontiguousarray(msg[:nb])
             row = {"method": method, "codewords": nb}
             for path in ("stream", "edge"):
-                os.environ["SCALDPC_PATH"] = path
+                dec.configure(path=path)
                 for label, kw, iters in (("fixed100", dict(early_exit=False), 100), ("early", dict(early_exit=True), None)):
                     dec.decode_batch(x, **kw)  # warm-up (allocations)
                     reps = 5
@@ -107,7 +104,6 @@ def main():
             out.append(row)
             print(json.dumps(row), flush=True)
         dec.close()
-    os.environ.pop("SCALDPC_PATH", None)
 
 
 if __name__ == "__main__":
