@@ -217,3 +217,57 @@ def test_incremental_accumulator_keeps_one_decoder_alive(golden):
             assert ok == ref_ok and all(got[k] == v for k, v in ref_stats.items() if k in got), (len(acc), got, ref_stats)
     assert len(seen) >= 3
     acc.close()
+
+
+try:
+    from hypothesis import HealthCheck, given, settings
+    from hypothesis import strategies as st
+
+    @settings(max_examples=int(os.environ.get("SCALDPC_PROPERTY_EXAMPLES", "25")), deadline=None, derandomize=True,
+              suppress_health_check=list(HealthCheck))
+    @given(N=st.integers(300, 2200), W=st.integers(4, 12), r0=st.integers(1, 300), steps=st.lists(st.integers(1, 120), min_size=1, max_size=6),
+           omega=st.integers(2, 9), eps=st.sampled_from([0.0, 0.03]), method=st.sampled_from(["min_sum", "product_sum"]),
+           path=st.sampled_from(["auto", "stream", "edge"]), nb=st.sampled_from([1, 2, 5, 9, 70]), early=st.booleans(),
+           decode_between=st.booleans(), seed=st.integers(0, 9999))
+    def test_random_append_sequences_equal_fresh_decoders(N, W, r0, steps, omega, eps, method, path, nb, early, decode_between, seed):
+        """Random HQC-shaped graphs grown by random step sizes, decoded (or not) between the appends, on a random
+        kernel family and batch size: after the last append -- and after every one when `decode_between` -- the
+        live decoder equals a fresh one bit for bit.  Not decoding between appends exercises several appends
+        against stale full tables and tables that do not exist yet."""
+        R = r0 + sum(steps)
+        H, Hin, probs, msg, y = hqc_instance(N, W, min(R, N), omega, eps, nb, seed=seed)
+        R = Hin.m
+        sizes = [min(r0, R)]
+        for s_ in steps:
+            if sizes[-1] < R:
+                sizes.append(min(R, sizes[-1] + s_))
+
+        def graph(r):
+            rp = Hin.row_ptr[: r + 1]
+            cols = np.concatenate([Hin.col_idx[: rp[-1]].reshape(r, -1), N + np.arange(r, dtype=np.int32)[:, None]], axis=1)
+            return S.TannerGraph.from_csr(r, N + r, np.arange(r + 1, dtype=np.int64) * cols.shape[1], cols.reshape(-1))
+
+        def pr(r):
+            return np.concatenate([probs[:N], probs[N : N + r]])
+
+        def x(r):
+            return np.concatenate([msg[:, :N], msg[:, N : N + r]], axis=1)
+
+        with np.errstate(divide="ignore"):
+            live = bp.bp_decoder(graph(sizes[0]), max_iter=20, bp_method=method, channel_probs=pr(sizes[0]))
+            live.configure(path=path)
+            if decode_between:
+                live.decode_batch(x(sizes[0]), early_exit=early)
+            for prev, r in zip(sizes[:-1], sizes[1:]):
+                rp, ci = _rows_csr(graph(r), prev, r)
+                live.append_rows(rp, ci, N + r, probs[N + prev : N + r])
+                if decode_between or r == sizes[-1]:
+                    fresh = bp.bp_decoder(graph(r), max_iter=20, bp_method=method, channel_probs=pr(r))
+                    fresh.configure(path=path)
+                    a = live.decode_batch(x(r), early_exit=early, want_llr=True)
+                    b = fresh.decode_batch(x(r), early_exit=early, want_llr=True)
+                    fresh.close()
+                    _same(a, b, (N, W, sizes, r, method, path, nb, early))
+            live.close()
+except ImportError:  # hypothesis is optional
+    pass
