@@ -60,9 +60,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--trials", type=int, default=65536, help="hqc128_mc: total trials over all ranks")
-    ap.add_argument("--mc-batch", type=int, default=32768, help="hqc128_mc: trials per device call (the stragglers "
-                    "of one call share its compact second pass, so larger is better: 190k/229k/240k trials/s at "
-                    "4096/16384/65536)")
+    ap.add_argument("--mc-batch", type=int, default=131072, help="hqc128_mc: trials per device call (the stragglers "
+                    "of one call share its compact passes, so larger is better: 356k / 365k / 371k / 367k trials/s at "
+                    "32768 / 131072 / 262144 / 524288, profiles/r02/mc_batch_sweep.log)")
     ap.add_argument("--pmc", choices=["live", "file", "off"], default="live", help="roofline.traffic: 'live' = two short "
                     "rocprofv3 --pmc child runs (FETCH_SIZE, WRITE_SIZE) of this very workload before the timed run "
                     "(N=1 only; falls back to 'file'), 'file' = the committed profiles/*_pmc_traffic_*.json, 'off' = null")

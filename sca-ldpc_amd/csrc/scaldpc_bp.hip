@@ -261,8 +261,9 @@ int grow(T **p, size_t *cap, size_t need)
     if (need <= *cap && *p) return 0;
     dev_free(*p);
     *cap = 0;
-    SC_TRY(dev_alloc(p, need));
-    *cap = need;
+    const size_t want = need + need / 8;  // a little headroom: the buffers of a decoder whose graph grows would otherwise be re-made at every step
+    SC_TRY(dev_alloc(p, want));
+    *cap = want;
     return 0;
 }
 
@@ -532,8 +533,9 @@ int ensure_el(scaldpc_bp *h, int nb)
     if (need > h->cap_el || !h->d_emsg) {
         dev_free(h->d_emsg);
         h->cap_el = 0;
-        SC_TRY(dev_alloc(&h->d_emsg, need));
-        h->cap_el = need;
+        const size_t want = h->incremental ? need + need / 4 : need;  // room for the edges still to come
+        SC_TRY(dev_alloc(&h->d_emsg, want));
+        h->cap_el = want;
     }
     return 0;
 }
