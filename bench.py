@@ -559,16 +559,16 @@ def pmc_traffic(workload, batch, swept, kernel):
     profiles/microbench), recorded under profiles/ for exactly this workload geometry.
     Counters cannot be read from inside the process, so this is the committed measurement,
     or None when the run's geometry differs from the profiled one."""
-    try:
-        d = json.load(open(os.path.join(ROOT, "profiles", f"r01_pmc_traffic_{workload}.json")))
-        if d["batch"] == batch and d["tile_group_codewords"] == swept:
-            # `kernel`: name prefix; the steady-state instantiation is the one whose last template
-            # argument (FIRST: inputs are the priors) is false
-            for name, v in d["kernels"].items():
-                if name.startswith(kernel) and not name.endswith("true>"):
-                    return v["traffic_bytes"]
-    except Exception:
-        pass
+    for path in (os.path.join(ROOT, "profiles", "r02", f"pmc_traffic_{workload}.json"),
+                 os.path.join(ROOT, "profiles", f"r01_pmc_traffic_{workload}.json")):
+        try:
+            d = json.load(open(path))
+            if d["batch"] == batch and d["tile_group_codewords"] == swept:
+                for name, v in d["kernels"].items():  # name prefix; the steady-state instantiation (FIRST = false)
+                    if name.startswith(kernel) and not name.endswith("true>"):
+                        return v["traffic_bytes"]
+        except Exception:
+            pass
     return None
 
 
