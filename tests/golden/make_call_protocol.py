@@ -41,6 +41,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 CALLS = []
+RECORD = [True]  # the four pinned entry points are recorded call by call; the command-body sweeps below only by their answers
 
 
 def describe(x):
@@ -109,7 +110,8 @@ def main():
                 "channel_probs_runs": runs_of(a["channel_probs"]) if a["channel_probs"][0] is not None else None,
                 "decode": [],
             }
-            CALLS.append(self.rec)
+            if RECORD[0]:
+                CALLS.append(self.rec)
             self.g = S.TannerGraph.from_dense(H)
             cp = a["channel_probs"]
             self.probs = np.asarray(cp, dtype=np.float64) if cp[0] is not None else np.full(self.g.n, float(a["error_rate"]))
@@ -122,7 +124,8 @@ def main():
                 r = pyoracle.bp_decode_batch(self.g, self.probs, (v[None, :] & 1).astype(np.uint8), kind, self.max_iter,
                                              "product_sum", dtype="f64", threads=1)
             out = r["bits"][0].astype(int)
-            self.rec["decode"].append({"arg": describe(v), "ones_in": [int(i) for i in np.flatnonzero(v)],
+            if RECORD[0]:
+                self.rec["decode"].append({"arg": describe(v), "ones_in": [int(i) for i in np.flatnonzero(v)],
                                        "ret": describe(out), "ones_out": [int(i) for i in np.flatnonzero(out)],
                                        "converged": int(r["converged"][0]), "iters": int(r["iters"][0])})
             return out
@@ -196,9 +199,35 @@ def main():
     answers["test_hqc_decode_full_example"] = bool(ref_hqc.test_hqc_decode_full_example(0))
     mark("test_hqc_decode_full_example (hqc.py:1277-1311)", n0)
 
+    # ---- the bodies of main.py's four FER commands (main.py:189-276; BASELINE config 1 is the first with
+    # --error-file binary_distr.txt), executed with the reference's own generators, ErrorsProvider and
+    # simulate_frame_error_rate exactly as those bodies call them.  main.py itself is not imported (it pulls in
+    # plotting and liboqs modules that are not installed); only the success counts are kept: the build's own
+    # driver must reproduce them on the HIP decoder (tests/test_driver_gpu.py).
+    RECORD[0] = False
+    bodies = {}
+    runs = 40
+    cmds = {
+        "regular_ldpc_code": lambda rng: make_code.make_regular_ldpc_parity_check_matrix(300, 150, 3, 6, rng),
+        "regular_ldpc_code_identity": lambda rng: make_code.make_regular_ldpc_parity_check_matrix_identity(300, 150, 3, 6, rng),
+        "qc_ldpc_code": lambda rng: make_code.make_qc_parity_check_matrix(block_len=500, column_weight=3, num_blocks=2, rng=rng),
+        "official_example": lambda rng: rep_code(13),
+    }
+    noise = {"error_file=binary_distr.txt": dict(error_rate=0.0, error_file=os.path.join(REF, "binary_distr.txt")),
+             "error_rate=0.03": dict(error_rate=0.03, error_file=None)}
+    for cname, mk in cmds.items():
+        for nname, nz in noise.items():
+            rng = utils.make_random_state(0)  # --seed 0
+            ep = ref_decode.ErrorsProvider(nz["error_rate"], nz["error_file"], rng)  # as the command bodies do, before H
+            H = mk(rng)
+            bodies[f"{cname} {nname}"] = int(ref_decode.simulate_frame_error_rate(H, ep, runs, rng))
+    RECORD[0] = True
+    answers["main_py_command_bodies"] = {"seed": 0, "runs": runs, "successes": bodies}
+    print("command bodies:", bodies)
+
     expected = {"simulate_frame_error_rate": 100, "simulate_frame_error_rate_rust": 1, "test_hqc_decode_toy_example": True,
                 "test_hqc_decode_full_example": True}
-    assert answers == expected, answers
+    assert {k: v for k, v in answers.items() if k != "main_py_command_bodies"} == expected, answers
     out = {"note": "minted by tests/golden/make_call_protocol.py from the reference's own drivers running on the drop-in "
                    "modules with oracle-backed recording doubles; data only (call forms, inputs, returned values)",
            "answers": answers, "calls": CALLS}

@@ -137,3 +137,29 @@ def test_kyber_channel_probabilities_layout():
     co, cs = drv.kyber_channel_probabilities(s, ss, 6, 2)
     assert co.shape == (768, 5) and cs.shape == (512, 25) and co.dtype == np.float32
     assert np.allclose(co[256 + 7], s[1][7]) and np.allclose(cs[3], ss[3][::-1])
+
+
+def _command_body_cases(golden, tmp_path):
+    """(name, callable returning the success count) for the eight main.py command-body runs whose answers the
+    REFERENCE's own driver gave in the build container (tests/golden/make_call_protocol.py)."""
+    import json, os
+
+    proto = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "call_protocol.json")))
+    body = proto["answers"]["main_py_command_bodies"]
+    f = tmp_path / "binary_distr.txt"
+    f.write_text("\n".join(str(r[0]) for r in golden["distr_files"]["binary_distr"]))
+    cmds = {"regular_ldpc_code": drv.regular_ldpc_code, "regular_ldpc_code_identity": drv.regular_ldpc_code_identity,
+            "qc_ldpc_code": drv.qc_ldpc_code, "official_example": drv.official_example}
+    for key, want in body["successes"].items():
+        cname, noise = key.split(" ")
+        kw = dict(error_rate=0.0, error_file=str(f)) if noise.startswith("error_file") else dict(error_rate=0.03)
+        yield key, want, (lambda c=cmds[cname], k=kw, **extra: c(body["seed"], body["runs"], **k, **extra))
+
+
+def test_command_bodies_reproduce_the_reference_drivers_answers(golden, tmp_path):
+    """main.py:189-276 (BASELINE config 1 = regular_ldpc_code with binary_distr.txt): the build's driver on the
+    float64 oracle decoder returns the success counts the reference's own generators + ErrorsProvider +
+    simulate_frame_error_rate returned on the same decoder -- same code construction, same noise stream,
+    same loop."""
+    for key, want, run in _command_body_cases(golden, tmp_path):
+        assert run(bp_decoder=OracleBp) == want, key

@@ -73,3 +73,13 @@ def test_incremental_accumulator_full_example(golden):
     assert found
     assert [r["checks"] for r in acc.decoder_stats][:3] == [50, 100, 150]
     assert acc.decoder_stats[-1]["good_flips"] == len(y) and acc.decoder_stats[-1]["bad_flips"] == 0
+
+
+def test_command_bodies_reproduce_the_reference_drivers_answers_on_the_gpu(golden, tmp_path):
+    """The same eight main.py command-body runs (tests/test_driver.py) on the HIP decoder: the success counts
+    of the REFERENCE's driver (0 / 40 / 0 / 8 / 0 / 1 / 40 / 40 of 40 frames; fp32 tanh rule here, float64
+    ratio domain there)."""
+    from test_driver import _command_body_cases
+
+    for key, want, run in _command_body_cases(golden, tmp_path):
+        assert run() == want, key
