@@ -368,7 +368,7 @@ def pmc_live(workload):
                    "--", sys.executable, os.path.abspath(__file__), "--pmc-child", "--workload", workload, "--batch", "256",
                    "--no-cpu-baseline", "--pmc", "off", "--parity-rows", "0"]
             try:
-                r = subprocess.run(cmd, env=env, cwd="/tmp", capture_output=True, text=True, timeout=420)
+                r = subprocess.run(cmd, env=env, cwd="/tmp", capture_output=True, text=True, timeout=240)  # (a pass takes 10-20 s)
             except Exception:
                 return None
             if r.returncode != 0:
