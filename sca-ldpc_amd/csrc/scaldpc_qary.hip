@@ -612,21 +612,26 @@ __global__ __launch_bounds__(64) void k_q_special_check_tree(const int *__restri
             dg[j] = tt % QB;
             tt /= QB;
             al[j] = Ab[j * QB + dg[j]];
-            ml[j] = INFINITY;
+            ml[j] = Bb[(size_t)(j * QB + dg[j]) * 64 + lane];  // continue from the lane's table entry (see below)
             P += al[j];  // ((0 + a_0) + a_1) + ...
             dsum += dg[j] - B;
         }
         for (int d3 = 0; d3 < QB; d3++) {
             const float a3 = Ab[NL * QB + d3];
             const float P3 = P + a3;
-            float m3 = INFINITY;
             // row-sum symbol of (.., d3, d4, d5): BSUM - (dsum + (d3-B) + (d4-B) + (d5-B)) = top - (d4 + d5)
             const int top = BSUM - (dsum + d3 - B) + 2 * B;
+            // the running minima of this block START from the lane's table entries (read up front, together
+            // with the alpha window), so that the commit at the end is a plain store: no read-modify-write
+            // chain of LDS latencies behind the arithmetic
+            float *const p3 = &Bb[(size_t)(NL * QB + d3) * 64 + lane];
+            float *const ps0 = &Bs[(size_t)top * 64 + lane];
+            float m3 = *p3;
             float aw[WIN], mw[WIN];
 #pragma unroll
             for (int u = 0; u < WIN; u++) {
                 aw[u] = As[top - u];
-                mw[u] = INFINITY;
+                mw[u] = ps0[-(ptrdiff_t)u * 64];
             }
 #pragma unroll
             for (int d4 = 0; d4 < QB; d4++) {
@@ -642,19 +647,12 @@ __global__ __launch_bounds__(64) void k_q_special_check_tree(const int *__restri
                     mw[d4 + d5] = vmin(mw[d4 + d5], S - aw[d4 + d5]);
                 }
             }
-            float *p3 = &Bb[(size_t)(NL * QB + d3) * 64 + lane];
-            *p3 = vmin(*p3, m3);
+            *p3 = m3;
 #pragma unroll
-            for (int u = 0; u < WIN; u++) {
-                float *ps = &Bs[(size_t)(top - u) * 64 + lane];
-                *ps = vmin(*ps, mw[u]);
-            }
+            for (int u = 0; u < WIN; u++) ps0[-(ptrdiff_t)u * 64] = mw[u];
         }
 #pragma unroll
-        for (int j = 0; j < NL; j++) {
-            float *pj = &Bb[(size_t)(j * QB + dg[j]) * 64 + lane];
-            *pj = vmin(*pj, ml[j]);
-        }
+        for (int j = 0; j < NL; j++) Bb[(size_t)(j * QB + dg[j]) * 64 + lane] = ml[j];
     }
     // combine the lanes' partial minima (exact) and write c2v in place
     for (int i = 0; i < (NB - 2) * QB; i++) {
