@@ -32,7 +32,7 @@ def main():
     H = g.to_dense(np.int8)
     rng = np.random.RandomState(10)
     dec = qary.decoder_class("DecoderN1280R512SW6")(H, iters)
-    for batch in (1, 16, 64, 256):
+    for batch in ((256,) if len(sys.argv) > 3 else (1, 16, 64, 256)):  # (a third argument: batch 256 only, for counter passes)
         pb = rng.dirichlet(np.ones(5), size=(batch, 768)).astype(np.float32)
         ps = rng.dirichlet(np.ones(25), size=(batch, 512)).astype(np.float32)
         res, out = {}, {}

@@ -17,10 +17,11 @@ from collections import defaultdict
 
 def main():
     src, dst = sys.argv[1:3]
+    prefixes = tuple(sys.argv[3].split(",")) if len(sys.argv) > 3 else ("k_var", "k_check")
     tot, cnt = defaultdict(lambda: defaultdict(float)), defaultdict(lambda: defaultdict(int))
     for r in csv.DictReader(open(src)):
         name = re.sub(r"^void ", "", r["Kernel_Name"].replace("(anonymous namespace)::", "")).split("(")[0]
-        if not name.startswith(("k_var", "k_check")) or name.endswith("true>"):
+        if not name.startswith(prefixes) or name.endswith("true>"):
             continue
         key = (name, r["Grid_Size"])
         tot[key][r["Counter_Name"]] += float(r["Counter_Value"])
@@ -42,6 +43,8 @@ def main():
             if avg.get("SQ_WAVES"):
                 row["quad_cycles_per_wave"] = wc / avg["SQ_WAVES"]
                 row["valu_instructions_per_wave"] = avg.get("SQ_INSTS_VALU", 0.0) / avg["SQ_WAVES"]
+                if "SQ_INSTS_LDS" in avg:
+                    row["lds_instructions_per_wave"] = avg["SQ_INSTS_LDS"] / avg["SQ_WAVES"]
         out[name] = row
     json.dump(out, open(dst, "w"), indent=1)
     for k, v in out.items():
