@@ -565,8 +565,8 @@ __global__ __launch_bounds__(64) void k_q_special_check_wave(const int *__restri
 // Per assignment: 2 adds + (NB + 1) subs + (NB + 1) mins = 16 VALU operations with register operands
 // (the generic wave kernel above: ~20 LDS accesses and ~100 integer / address operations).
 // wave = (check, codeword); LDS: Ab[NB*QB] + As[QS] floats (shared), per-lane tables
-// Bb[(NB-2)*QB][64] and Bs[QS][64]; the partial minima of the 64 lanes are combined with wave
-// shuffles at the end (exact), so the messages are bit-identical to the other kernels'.
+// Bb[NB*QB][64] and Bs[QS][64]; the partial minima of the 64 lanes are combined at the end by a
+// transposed walk over the tables (exact), so the messages are bit-identical to the other kernels'.
 // grid (R, batch), block 64.  Rows whose degree is not NB + 1 are left to k_q_special_check_wave.
 // ---------------------------------------------------------------------------
 template <int QB, int NB>
@@ -580,8 +580,8 @@ __global__ __launch_bounds__(64) void k_q_special_check_tree(const int *__restri
     const int QS = 2 * BSUM + 1;
     float *Ab = (float *)smem;               // [NB][QB]
     float *As = Ab + NB * QB;                // [QS]
-    float *Bb = As + QS;                     // [(NB - 2) * QB][64]   tables of digits 0 .. NB-3
-    float *Bs = Bb + (size_t)(NB - 2) * QB * 64;  // [QS][64]
+    float *Bb = As + QS;                     // [NB * QB][64]   per-lane tables of the digits (the last two rows only at the end)
+    float *Bs = Bb + (size_t)NB * QB * 64;   // [QS][64]
     const int c = blockIdx.x;
     const long b = blockIdx.y;
     const int e0 = row_ptr[c], nb = row_ptr[c + 1] - e0 - 1;
@@ -654,22 +654,34 @@ __global__ __launch_bounds__(64) void k_q_special_check_tree(const int *__restri
 #pragma unroll
         for (int j = 0; j < NL; j++) Bb[(size_t)(j * QB + dg[j]) * 64 + lane] = ml[j];
     }
-    // combine the lanes' partial minima (exact) and write c2v in place
-    for (int i = 0; i < (NB - 2) * QB; i++) {
-        const float v = wave_min(Bb[(size_t)i * 64 + lane]);
-        if (lane == 0) msg[((size_t)(e0 + i / QB) * W + i % QB) * Bp + b] = v;
-    }
+    // Combine the 64 lanes' partial minima (exact: min is order-free) and write c2v in place.  The tables
+    // are [slot][lane] in LDS: lane s takes slot s and walks the 64 entries of its row -- rotated by its own
+    // index, so that the lanes of a wave hit 64 different banks -- instead of a butterfly of 6 cross-lane
+    // shuffles per slot (each a dependent LDS-crossbar round trip: 480 of them per wave were half a wave's
+    // life, profiles/r02/sq_counters_kyber_tree.json).  The two unrolled digits' register minima go through
+    // the table as well (rows NB-2 and NB-1 of Bb).
 #pragma unroll
     for (int q = 0; q < QB; q++) {
-        const float v4 = wave_min(b4[q]), v5 = wave_min(b5[q]);
-        if (lane == 0) {
-            msg[((size_t)(e0 + NB - 2) * W + q) * Bp + b] = v4;
-            msg[((size_t)(e0 + NB - 1) * W + q) * Bp + b] = v5;
-        }
+        Bb[(size_t)((NB - 2) * QB + q) * 64 + lane] = b4[q];
+        Bb[(size_t)((NB - 1) * QB + q) * 64 + lane] = b5[q];
     }
-    for (int i = 0; i < QS; i++) {
-        const float v = wave_min(Bs[(size_t)i * 64 + lane]);
-        if (lane == 0) msg[((size_t)(e0 + NB) * W + i) * Bp + b] = v;
+    __syncthreads();
+    const int nslots = NB * QB + QS;  // Bb and Bs are contiguous: one table of nslots rows
+    for (int s = lane; s < nslots; s += 64) {
+        const float *row = Bb + (size_t)s * 64;
+        float m0 = INFINITY, m1 = INFINITY, m2 = INFINITY, m3 = INFINITY;
+#pragma unroll 4
+        for (int l = 0; l < 64; l += 4) {
+            m0 = vmin(m0, row[(l + lane) & 63]);
+            m1 = vmin(m1, row[(l + 1 + lane) & 63]);
+            m2 = vmin(m2, row[(l + 2 + lane) & 63]);
+            m3 = vmin(m3, row[(l + 3 + lane) & 63]);
+        }
+        const float v = vmin(vmin(m0, m1), vmin(m2, m3));
+        if (s < NB * QB)
+            msg[((size_t)(e0 + s / QB) * W + s % QB) * Bp + b] = v;
+        else
+            msg[((size_t)(e0 + NB) * W + (s - NB * QB)) * Bp + b] = v;
     }
 }
 
@@ -965,7 +977,7 @@ int qary_run(scaldpc_qary *h, const float *pmf_b, const float *pmf_s, int batch,
                                    batch, h->d_err);
             else if (h->special && tree_nb) {
                 // the Kyber shape: tree walk for the rows of 6 coefficient edges, the generic wave kernel for any others
-                const size_t tree_lds = ((size_t)tree_nb * h->Q + h->QS + (size_t)((tree_nb - 2) * h->Q + h->QS) * 64) * 4;
+                const size_t tree_lds = ((size_t)tree_nb * h->Q + h->QS + (size_t)(tree_nb * h->Q + h->QS) * 64) * 4;
                 hipLaunchKernelGGL((k_q_special_check_tree<5, 6>), dim3(h->R, batch), dim3(64), tree_lds, s, h->d_row_ptr, h->d_msg,
                                    h->BSUM, h->W, Bp);
                 if (h->mindc - 1 != tree_nb || h->maxdc - 1 != tree_nb)
