@@ -44,6 +44,33 @@ int main(void)
     printf("bad input kind -> %d (%s)\n", rc, scaldpc_last_error());
     scaldpc_bp_destroy(h);
 
+    /* a graph that grows (hqc.py:885-908): rep_code(7) built from its first 3 checks, the other 3 appended
+     * -- bringing columns 4..6 -- then decoded with the tile kernels (whose tables are rebuilt on demand) */
+    {
+        enum { N2 = 7, M2 = 6, HALF = 3 };
+        int32_t rp[M2 + 1], ci[2 * M2];
+        for (int i = 0; i <= M2; i++) rp[i] = 2 * i;
+        for (int i = 0; i < M2; i++) { ci[2 * i] = i; ci[2 * i + 1] = i + 1; }
+        scaldpc_bp *g = NULL;
+        CHECK(scaldpc_bp_create(HALF, HALF + 1, 2 * HALF, rp, ci, &g));
+        double p4[HALF + 1] = {0.05, 0.05, 0.05, 0.05}, ptail[N2 - HALF - 1] = {0.05, 0.05, 0.05};
+        CHECK(scaldpc_bp_set_channel_probs(g, p4));
+        int32_t rp_new[HALF + 1] = {0, 2, 4, 6};
+        CHECK(scaldpc_bp_append_rows(g, HALF, rp_new, ci + 2 * HALF, N2));
+        CHECK(scaldpc_bp_set_channel_probs_tail(g, HALF + 1, N2 - HALF - 1, ptail));
+        CHECK(scaldpc_bp_configure(g, "path", "stream"));
+        uint8_t s2[M2] = {0, 0, 0, 1, 1, 0}, b2[N2]; /* one error at position 4 */
+        CHECK(scaldpc_bp_decode_batch(g, s2, SCALDPC_IN_SYNDROME, 1, N2, SCALDPC_BP_MIN_SUM, 1.0f, SCALDPC_F_EARLY_EXIT, NULL,
+                                      b2, NULL, NULL, NULL));
+        int good = 1;
+        for (int j = 0; j < N2; j++) good &= b2[j] == (j == 4);
+        int32_t where[4];
+        CHECK(scaldpc_bp_device_of(g, where));
+        printf("append: error at 4 %s, handle on device %d, graph on %d\n", good ? "found" : "MISSED", where[0], where[1]);
+        scaldpc_bp_destroy(g);
+        if (!good || where[0] != where[1]) return 3;
+    }
+
     /* q-ary: decoder.rs:771-799, one bad symbol, Q = 15 */
     const int8_t H[3][6] = {{1, 1, 1, 1, 0, 0}, {0, 0, 1, 1, 0, 1}, {1, 0, 0, 1, 1, 0}};
     scaldpc_qary *q = NULL;
@@ -59,5 +86,11 @@ int main(void)
     for (int v = 0; v < 6; v++) zeros &= out[v] == 0;
     printf("qary: all-zero decoding %s\n", zeros ? "yes" : "no");
     scaldpc_qary_destroy(q);
+    /* Decoder::into_llr alone (decoder.rs:744-768): ln(0.14 / 0.02) = 1.9459101 in f32, ln(max / 0) = +inf */
+    const float row[15] = {0, 0, 0, 0, .14f, .14f, .14f, .14f, .14f, .14f, .14f, .02f, 0, 0, 0};
+    float llr[15];
+    CHECK(scaldpc_qary_into_llr(row, 1, 15, 0, NULL, llr));
+    printf("into_llr: %.7f %s\n", (double)llr[11], llr[0] > 3e38f ? "inf" : "finite");
+    if (llr[11] != 1.9459101f || !(llr[0] > 3e38f) || llr[4] != 0.0f) return 4;
     return (ok == BATCH && rc == SCALDPC_EINVAL && zeros) ? 0 : 2;
 }

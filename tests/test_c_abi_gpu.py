@@ -20,3 +20,4 @@ def test_plain_c_client(tmp_path):
     assert out.returncode == 0, out.stdout + out.stderr
     assert "bp: 70/70 single errors corrected" in out.stdout
     assert "bad input kind -> 1" in out.stdout and "qary: all-zero decoding yes" in out.stdout
+    assert "append: error at 4 found" in out.stdout and "into_llr: 1.9459101 inf" in out.stdout
