@@ -386,7 +386,7 @@ int ensure_tile_tables(scaldpc_bp *h)
     // (the records carry the column id, so the order is free; results cannot depend on it).
     std::vector<int> order_buf;
     const int *vlist = hv.list.data();
-    if (h->kn.var_order == 1 && !hv.list.empty()) {
+    if ((h->kn.var_order & 1) && !hv.list.empty()) {
         order_buf = hv.list;
         size_t i = 0;
         while (i < order_buf.size()) {
@@ -417,6 +417,13 @@ int ensure_tile_tables(scaldpc_bp *h)
             for (int k = 0; k < VAR_INLINE; k++) md[4 + k] = k < d ? relaid[pos + k] : 0;
             pos += d;
         }
+    }
+    if (h->kn.var_order & 2) {
+        // heaviest columns FIRST: the waves that start last are then the cheapest ones (degree-1 identity
+        // columns), which shortens the tail of the launch (longest-processing-time-first)
+        const size_t nrec = (size_t)4 * hv.bk.blk[hv.bk.nb];
+        for (size_t i = 0, j = nrec ? nrec - 1 : 0; i < j; i++, j--)
+            std::swap_ranges(meta + i * VAR_REC, meta + (i + 1) * VAR_REC, meta + j * VAR_REC);
     }
     SC_TRY(upload_table(&h->d_tile_tab, host, total));
     h->d_var_meta = h->d_tile_tab + o_var_meta;
