@@ -173,8 +173,9 @@ int scaldpc_bp_last_stats(scaldpc_bp *h, int64_t *out);
  *   "el_fuse"       1 = two-launch early-exit loop of the row-parallel path (default), 0 = four-launch
  *   "compact_after" iteration from which stragglers may be handed to a compact pass (default 4, 0 = never)
  *   "minsum_loop"   1 = loop form of the min-sum check kernel (A/B)
- *   "var_order"     order of the columns of one degree in a variable-node launch: 0 ascending column,
- *                   1 by first edge id (default)
+ *   "var_order"     launch order of the columns in a variable-node pass: bit 0 = inside a degree by first
+ *                   edge id (else by column id), bit 1 = heaviest columns first; -1 (default) = auto:
+ *                   2 when a tile group runs as one stream lane, 1 otherwise
  *   "var_form"      variable-node kernel: 1 = a wave fetches all its edge ids up front as wide scalar loads
  *                   (default), 0 = one scalar load per edge.  Results never depend on any of these. */
 int scaldpc_bp_configure(scaldpc_bp *h, const char *key, const char *value);

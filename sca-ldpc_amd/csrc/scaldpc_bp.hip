@@ -70,7 +70,8 @@ struct Knobs {
     int el_fuse = 1;          // early-exit row-parallel loop: fused two-launch form
     int compact_after = -1;   // -1 = default (4); 0 = no compact pass
     int minsum_loop = 0;      // loop form of the min-sum check kernel (A/B knob)
-    int var_order = 1;        // k_var launch order inside a degree: 0 = ascending column id, 1 = by first edge id (default)
+    int var_order = -1;       // k_var launch order: bit 0 = inside a degree by first edge id, bit 1 = heaviest columns first; -1 = auto
+    int tanh_occ = 0;         // tanh check kernel: 3 = compiled for 3 waves per SIMD (A/B)
     int var_form = 1;         // k_var: 0 = ids fetched edge by edge, 1 = all ids up front as wide scalar loads (default)
 };
 
@@ -202,6 +203,7 @@ bool set_knob(Knobs &k, const char *key, const char *val)
     else if (!strcmp(key, "minsum_loop")) k.minsum_loop = (int)x != 0;
     else if (!strcmp(key, "var_order")) k.var_order = (int)x;
     else if (!strcmp(key, "var_form")) k.var_form = (int)x;
+    else if (!strcmp(key, "tanh_occ")) k.tanh_occ = (int)x;
     else return false;
     return true;
 }
@@ -211,7 +213,7 @@ void knobs_from_env(Knobs &k)
     static const char *const names[][2] = {{"SCALDPC_PATH", "path"}, {"SCALDPC_SPLIT", "split"},
                                            {"SCALDPC_GROUP_MB", "group_mb"}, {"SCALDPC_EL_MAX", "el_max"},
                                            {"SCALDPC_EL_FUSE", "el_fuse"}, {"SCALDPC_COMPACT_AFTER", "compact_after"},
-                                           {"SCALDPC_VAR_ORDER", "var_order"}, {"SCALDPC_VAR_FORM", "var_form"}};
+                                           {"SCALDPC_VAR_ORDER", "var_order"}, {"SCALDPC_VAR_FORM", "var_form"}, {"SCALDPC_TANH_OCC", "tanh_occ"}};
     for (auto &nm : names)
         if (const char *e = getenv(nm[0])) (void)set_knob(k, nm[1], e);
     if (getenv("SCALDPC_MINSUM_LOOP")) k.minsum_loop = 1;  // presence switches it on, as before
@@ -386,7 +388,14 @@ int ensure_tile_tables(scaldpc_bp *h)
     // (the records carry the column id, so the order is free; results cannot depend on it).
     std::vector<int> order_buf;
     const int *vlist = hv.list.data();
-    if ((h->kn.var_order & 1) && !hv.list.empty()) {
+    // auto: a tile group that runs as ONE stream lane (a tile too large to share the cache with a second one:
+    // the HQC-256 graph) has nothing to fill the tail of its launches with, so its heaviest columns go first
+    // (measured 321.5 -> 315.5 ms per step, k_var 51.5 -> 49.9 us); with two lanes the other lane's kernel
+    // lives in that tail and the same order costs 0.8 % (HQC-128: 95.2 -> 96.0 ms): there the columns of a
+    // degree are ordered by their first edge instead (profiles/r02/ab_*order*.json)
+    const bool single_lane = auto_group(h, 1 << 20) < 2 || h->kn.split < 2;
+    const int var_order = h->kn.var_order >= 0 ? h->kn.var_order : (single_lane ? 2 : 1);
+    if ((var_order & 1) && !hv.list.empty()) {
         order_buf = hv.list;
         size_t i = 0;
         while (i < order_buf.size()) {
@@ -418,7 +427,7 @@ int ensure_tile_tables(scaldpc_bp *h)
             pos += d;
         }
     }
-    if (h->kn.var_order & 2) {
+    if (var_order & 2) {
         // heaviest columns FIRST: the waves that start last are then the cheapest ones (degree-1 identity
         // columns), which shortens the tail of the launch (longest-processing-time-first)
         const size_t nrec = (size_t)4 * hv.bk.blk[hv.bk.nb];
@@ -608,7 +617,10 @@ int launch_check(scaldpc_bp *h, int method, float alpha, int G, const u64 *synd_
 #define TANH_LAUNCH(CAP, F)                                                                                         \
     hipLaunchKernelGGL((k_check_tanh<CAP, F>), grid, dim3(256), 0, s, h->row_bk, h->d_row_list, h->d_row_ptr, msg0, \
                        scr0, synd_g, done_g, skip_done, h->m, h->E, h->d_col_idx, h->d_prior)
-        if (h->max_row_deg <= 16) {
+        if (h->kn.tanh_occ == 3 && h->max_row_deg > 32 && !first) {  // A/B: register budget for 3 waves per SIMD
+            hipLaunchKernelGGL((k_check_tanh<64, false, 3>), grid, dim3(256), 0, s, h->row_bk, h->d_row_list, h->d_row_ptr, msg0,
+                               scr0, synd_g, done_g, skip_done, h->m, h->E, h->d_col_idx, h->d_prior);
+        } else if (h->max_row_deg <= 16) {
             if (first) TANH_LAUNCH(16, true); else TANH_LAUNCH(16, false);
         } else if (h->max_row_deg <= 32) {
             if (first) TANH_LAUNCH(32, true); else TANH_LAUNCH(32, false);
