@@ -71,7 +71,6 @@ struct Knobs {
     int compact_after = -1;   // -1 = default (4); 0 = no compact pass
     int minsum_loop = 0;      // loop form of the min-sum check kernel (A/B knob)
     int var_order = -1;       // k_var launch order: bit 0 = inside a degree by first edge id, bit 1 = heaviest columns first; -1 = auto
-    int tanh_occ = 0;         // tanh check kernel: 3 = compiled for 3 waves per SIMD (A/B)
     int var_form = 1;         // k_var: 0 = ids fetched edge by edge, 1 = all ids up front as wide scalar loads (default)
 };
 
@@ -203,7 +202,6 @@ bool set_knob(Knobs &k, const char *key, const char *val)
     else if (!strcmp(key, "minsum_loop")) k.minsum_loop = (int)x != 0;
     else if (!strcmp(key, "var_order")) k.var_order = (int)x;
     else if (!strcmp(key, "var_form")) k.var_form = (int)x;
-    else if (!strcmp(key, "tanh_occ")) k.tanh_occ = (int)x;
     else return false;
     return true;
 }
@@ -213,7 +211,7 @@ void knobs_from_env(Knobs &k)
     static const char *const names[][2] = {{"SCALDPC_PATH", "path"}, {"SCALDPC_SPLIT", "split"},
                                            {"SCALDPC_GROUP_MB", "group_mb"}, {"SCALDPC_EL_MAX", "el_max"},
                                            {"SCALDPC_EL_FUSE", "el_fuse"}, {"SCALDPC_COMPACT_AFTER", "compact_after"},
-                                           {"SCALDPC_VAR_ORDER", "var_order"}, {"SCALDPC_VAR_FORM", "var_form"}, {"SCALDPC_TANH_OCC", "tanh_occ"}};
+                                           {"SCALDPC_VAR_ORDER", "var_order"}, {"SCALDPC_VAR_FORM", "var_form"}};
     for (auto &nm : names)
         if (const char *e = getenv(nm[0])) (void)set_knob(k, nm[1], e);
     if (getenv("SCALDPC_MINSUM_LOOP")) k.minsum_loop = 1;  // presence switches it on, as before
@@ -617,10 +615,7 @@ int launch_check(scaldpc_bp *h, int method, float alpha, int G, const u64 *synd_
 #define TANH_LAUNCH(CAP, F)                                                                                         \
     hipLaunchKernelGGL((k_check_tanh<CAP, F>), grid, dim3(256), 0, s, h->row_bk, h->d_row_list, h->d_row_ptr, msg0, \
                        scr0, synd_g, done_g, skip_done, h->m, h->E, h->d_col_idx, h->d_prior)
-        if (h->kn.tanh_occ == 3 && h->max_row_deg > 32 && !first) {  // A/B: register budget for 3 waves per SIMD
-            hipLaunchKernelGGL((k_check_tanh<64, false, 3>), grid, dim3(256), 0, s, h->row_bk, h->d_row_list, h->d_row_ptr, msg0,
-                               scr0, synd_g, done_g, skip_done, h->m, h->E, h->d_col_idx, h->d_prior);
-        } else if (h->max_row_deg <= 16) {
+        if (h->max_row_deg <= 16) {
             if (first) TANH_LAUNCH(16, true); else TANH_LAUNCH(16, false);
         } else if (h->max_row_deg <= 32) {
             if (first) TANH_LAUNCH(32, true); else TANH_LAUNCH(32, false);

@@ -486,9 +486,8 @@ __device__ __forceinline__ void check_tanh_row_generic(float *p, float *sc, int 
 // CAP = largest degree compiled in (the register budget follows the widest instantiation,
 // so graphs with narrow rows get the high-occupancy build).
 // grid (bk.blk[nb], G), block 256 = 4 rows of one bucket.
-// OCC: minimum waves per SIMD the register allocation must leave room for (A/B knob `tanh_occ`; 1 = no constraint).
-template <int CAP, bool FIRST, int OCC = 1>
-__global__ __launch_bounds__(256, OCC) void k_check_tanh(Buckets bk, const int *__restrict__ list,
+template <int CAP, bool FIRST>
+__global__ __launch_bounds__(256) void k_check_tanh(Buckets bk, const int *__restrict__ list,
                                                     const int *__restrict__ row_ptr, float *msg, float *scratch,
                                                     const u64 *__restrict__ synd, const u64 *__restrict__ done,
                                                     int skip_done, int m, long E, const int *__restrict__ col_idx,
