@@ -71,6 +71,7 @@ struct Knobs {
     int compact_after = -1;   // -1 = default (4); 0 = no compact pass
     int minsum_loop = 0;      // loop form of the min-sum check kernel (A/B knob)
     int var_order = -1;       // k_var launch order: bit 0 = inside a degree by first edge id, bit 1 = heaviest columns first; -1 = auto
+    int speculate = 1;        // early-exit tile groups: stop at the hand-over point without polling once two groups in a row did (0 = always poll)
     int var_form = 1;         // k_var: 0 = ids fetched edge by edge, 1 = all ids up front as wide scalar loads (default)
 };
 
@@ -202,6 +203,7 @@ bool set_knob(Knobs &k, const char *key, const char *val)
     else if (!strcmp(key, "minsum_loop")) k.minsum_loop = (int)x != 0;
     else if (!strcmp(key, "var_order")) k.var_order = (int)x;
     else if (!strcmp(key, "var_form")) k.var_form = (int)x;
+    else if (!strcmp(key, "speculate")) k.speculate = (int)x != 0;
     else return false;
     return true;
 }
@@ -211,7 +213,7 @@ void knobs_from_env(Knobs &k)
     static const char *const names[][2] = {{"SCALDPC_PATH", "path"}, {"SCALDPC_SPLIT", "split"},
                                            {"SCALDPC_GROUP_MB", "group_mb"}, {"SCALDPC_EL_MAX", "el_max"},
                                            {"SCALDPC_EL_FUSE", "el_fuse"}, {"SCALDPC_COMPACT_AFTER", "compact_after"},
-                                           {"SCALDPC_VAR_ORDER", "var_order"}, {"SCALDPC_VAR_FORM", "var_form"}};
+                                           {"SCALDPC_VAR_ORDER", "var_order"}, {"SCALDPC_VAR_FORM", "var_form"}, {"SCALDPC_SPECULATE", "speculate"}};
     for (auto &nm : names)
         if (const char *e = getenv(nm[0])) (void)set_knob(k, nm[1], e);
     if (getenv("SCALDPC_MINSUM_LOOP")) k.minsum_loop = 1;  // presence switches it on, as before
@@ -791,9 +793,22 @@ int ensure_lanes(scaldpc_bp *h, int nl)
     if (nl > 1 && !h->ev_join[0]) SC_HIP(hipEventCreateWithFlags(&h->ev_join[0], hipEventDisableTiming));  // [0]: the fork event
     return 0;
 }
+// What the groups of one call learn from each other about polling (a poll drains the queue: the GPU idles
+// while the host turns around, ~4 % of a group's time on the config-5 sweep):
+//   hint   poll points before this iteration saw no codeword finish in earlier groups: skip them
+//   streak consecutive groups that handed a small remainder (<= 1/8) to the compact pass at `defer_after`:
+//          after two of them the next groups stop there WITHOUT polling (their stragglers are found from the
+//          done masks afterwards, as always), with a real poll every 16th group to keep the assumption honest.
+//          A group stopped on a wrong guess only sends more codewords to the compact pass, which decodes
+//          them from their inputs: results cannot change.
+struct PollState {
+    int hint = 1, streak = 0, since_poll = 0;
+};
+
 int iterate_tiles(scaldpc_bp *h, const TileState &st, int g0, int g, int max_iter, int method, float alpha, bool early,
-                  int defer_after, hipStream_t s, bool *deferred, int real_codewords, int *poll_hint)
+                  int defer_after, hipStream_t s, bool *deferred, int real_codewords, PollState *ps)
 {
+    int *const poll_hint = ps ? &ps->hint : nullptr;
     const int poll_every = 4;
     const int skip = early ? 1 : 0;
     const int nl = fixed_lanes(h, g);
@@ -856,6 +871,12 @@ int iterate_tiles(scaldpc_bp *h, const TileState &st, int g0, int g, int max_ite
         // a poll drains the queue (the GPU idles while the host turns around): skip the poll
         // points at which the call's earlier groups saw no codeword finish yet
         const bool poll = (it % poll_every == 0 || it == 1 || it == defer_after) && (!poll_hint || it >= *poll_hint);
+        if (early && !last && poll && ps && it == defer_after && defer_after > 0 && 2 * it < max_iter && ps->streak >= 2 &&
+            ps->since_poll < 15 && h->kn.speculate) {
+            ps->since_poll++;  // stop here unseen, as the last groups did
+            *deferred = true;
+            return join();
+        }
         if (early && !last && poll) {
             SC_TRY(join());
             SC_HIP(hipMemcpyAsync(h->h_remaining + it, h->d_remaining + it, sizeof(int), hipMemcpyDeviceToHost, s));
@@ -870,9 +891,14 @@ int iterate_tiles(scaldpc_bp *h, const TileState &st, int g0, int g, int max_ite
             // row-parallel kernels
             const bool shrinks = (rem + TW - 1) / TW < g || rem <= el_limit(h, method);
             if (defer_after > 0 && it >= defer_after && 2 * it < max_iter && 2 * rem <= real_codewords && shrinks) {
+                if (ps) {
+                    ps->streak = (it == defer_after && 8 * rem <= real_codewords) ? ps->streak + 1 : 0;
+                    ps->since_poll = 0;
+                }
                 *deferred = true;
                 return 0;
             }
+            if (ps && it >= defer_after) ps->streak = 0;
         }
     }
     return join();
@@ -881,7 +907,7 @@ int iterate_tiles(scaldpc_bp *h, const TileState &st, int g0, int g, int max_ite
 // el > 0: the group is ONE tile holding `el` codewords, decoded by the row-parallel kernels.
 int iterate_group(scaldpc_bp *h, const TileState &st, int g0, int g, int max_iter, int method, float alpha, bool early,
                   int defer_after, hipStream_t s, bool *deferred, int el = 0, int real_codewords = 0,
-                  int *poll_hint = nullptr)
+                  PollState *poll_hint = nullptr)
 {
     *deferred = false;
     if (!el)
@@ -953,7 +979,7 @@ int decode_level(scaldpc_bp *h, int lvl, const TileState &st, int batch, int T, 
     }
     std::vector<char> deferred_tile(T, 0);
     bool any = false;
-    int poll_hint = 1;
+    PollState poll_hint;
     for (int g0 = 0; g0 < T; g0 += Gl) {
         const int g = std::min(Gl, T - g0);
         const int real = std::min(batch - g0 * TW, g * TW);

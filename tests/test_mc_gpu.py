@@ -67,6 +67,9 @@ def test_config5_sweep_sheds_stragglers_twice(monkeypatch):
     a = dec.mc_hqc_run(8192, omega=omega, eps=0.05, seed=7)
     st = dec.last_stats()
     assert st["compacted"] > 0 and st["levels"] >= 2, st
+    dec.configure(speculate=0)  # every group polls at the hand-over point (instead of stopping there unseen after two that did)
+    c = dec.mc_hqc_run(8192, omega=omega, eps=0.05, seed=7)
+    assert np.array_equal(a["success"], c["success"]) and np.array_equal(a["iters"], c["iters"])
     dec.configure(compact_after=0)
     b = dec.mc_hqc_run(8192, omega=omega, eps=0.05, seed=7)
     assert dec.last_stats()["levels"] == 0
