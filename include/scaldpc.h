@@ -164,7 +164,8 @@ int scaldpc_bp_last_compacted(scaldpc_bp *h, int64_t *count);
 int scaldpc_bp_last_stats(scaldpc_bp *h, int64_t *out);
 /* Tuning / test knobs of one handle.  A new handle takes its defaults from the environment ONCE, at
  * creation (SCALDPC_PATH, SCALDPC_SPLIT, SCALDPC_GROUP_MB, SCALDPC_EL_MAX, SCALDPC_EL_FUSE,
- * SCALDPC_COMPACT_AFTER, SCALDPC_MINSUM_LOOP, SCALDPC_VAR_ORDER); the decode entry points never read
+ * SCALDPC_COMPACT_AFTER, SCALDPC_MINSUM_LOOP, SCALDPC_VAR_ORDER, SCALDPC_VAR_FORM, SCALDPC_SPECULATE); the
+ * decode entry points never read
  * the environment.  key / value (text):
  *   "path"          "auto" | "stream" (64-codeword tiles) | "edge" (row-parallel up to 64) | "lds"
  *   "split"         stream lanes per tile group (default 2)
@@ -177,7 +178,10 @@ int scaldpc_bp_last_stats(scaldpc_bp *h, int64_t *out);
  *                   edge id (else by column id), bit 1 = heaviest columns first; -1 (default) = auto:
  *                   2 when a tile group runs as one stream lane, 1 otherwise
  *   "var_form"      variable-node kernel: 1 = a wave fetches all its edge ids up front as wide scalar loads
- *                   (default), 0 = one scalar load per edge.  Results never depend on any of these. */
+ *                   (default), 0 = one scalar load per edge
+ *   "speculate"     1 (default) = an early-exit tile group stops at the hand-over point without polling the
+ *                   device once two groups in a row handed a small remainder to the compact pass there,
+ *                   0 = every group polls.  Results never depend on any of these. */
 int scaldpc_bp_configure(scaldpc_bp *h, const char *key, const char *value);
 /* Where a handle lives, out[4]: the device it was created on; the device (hipPointerGetAttributes)
  * of its graph allocation, of its message workspace and of its state planes (-1 = not allocated yet).
@@ -232,7 +236,9 @@ void scaldpc_qary_destroy(scaldpc_qary *h);
 int scaldpc_qary_into_llr(const float *pmf, int64_t rows, int32_t Q, uint32_t flags, void *stream, float *llr);
 /* Test / tuning knobs of one q-ary handle (defaults from SCALDPC_QARY_WAVE / SCALDPC_QARY_NO_UNROLL, read
  * once at creation): "wave" = -1 auto | 0 codeword per lane | 1 wave per (check, codeword);
- * "unroll" = 1 register-resident unrolled enumeration for small alphabets | 0 off. */
+ * "unroll" = 1 register-resident unrolled enumeration for small alphabets | 0 off;
+ * "tree" = 1 tree-walk check kernel for the Kyber shape (B = 2, six coefficient edges per check) | 0 off
+ * (SCALDPC_QARY_NO_TREE). */
 int scaldpc_qary_configure(scaldpc_qary *h, const char *key, const char *value);
 
 /* DecoderSpecial: H = [H' | I_R]; first N-R variables over [-B,B], last R over [-BSUM,BSUM]. */
