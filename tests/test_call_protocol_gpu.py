@@ -32,8 +32,10 @@ def test_protocol_answers_and_call_forms_bind_to_the_real_signatures():
     binds to the real classes' signatures (no GPU needed for that)."""
     import inspect
 
-    assert PROTOCOL["answers"] == {"simulate_frame_error_rate": 100, "simulate_frame_error_rate_rust": 1,
-                                   "test_hqc_decode_toy_example": True, "test_hqc_decode_full_example": True}
+    pinned = {k: v for k, v in PROTOCOL["answers"].items() if k != "main_py_command_bodies"}
+    assert pinned == {"simulate_frame_error_rate": 100, "simulate_frame_error_rate_rust": 1,
+                      "test_hqc_decode_toy_example": True, "test_hqc_decode_full_example": True}
+    assert len(PROTOCOL["answers"]["main_py_command_bodies"]["successes"]) == 8  # (reproduced in tests/test_driver*.py)
     bp = importlib.import_module("sca-ldpc_amd.bp")
     qary = importlib.import_module("sca-ldpc_amd.qary")
     for c in PROTOCOL["calls"]:
