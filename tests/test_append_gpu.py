@@ -271,3 +271,59 @@ try:
             live.close()
 except ImportError:  # hypothesis is optional
     pass
+
+
+def test_append_to_an_empty_graph_and_while_asynchronous_work_is_in_flight(oracle):
+    """Two corners: (i) a decoder built on a graph WITHOUT edges (one empty check) grows into a real one;
+    (ii) rows are appended right after SCALDPC_F_ASYNC decodes were enqueued on the caller's stream, with no
+    synchronisation in between -- the append must wait for them (their tables and buffers are being
+    replaced), and both the in-flight results and the later ones must be right."""
+    import torch
+
+    lib = importlib.import_module("sca-ldpc_amd._lib")
+    H, Hin, probs, msg, y = hqc_instance(997, 9, 400, 6, 0.03, 130, seed=51)
+    N = 997
+
+    def graph(r):
+        rp = Hin.row_ptr[: r + 1]
+        cols = np.concatenate([Hin.col_idx[: rp[-1]].reshape(r, -1), N + np.arange(r, dtype=np.int32)[:, None]], axis=1)
+        return S.TannerGraph.from_csr(r, N + r, np.arange(r + 1, dtype=np.int64) * cols.shape[1], cols.reshape(-1))
+
+    # (i) empty start: one check with no variables over the N secret columns
+    empty = S.TannerGraph.from_csr(1, N, np.zeros(2, dtype=np.int64), np.zeros(0, dtype=np.int32))
+    live = bp.bp_decoder(empty, max_iter=20, bp_method="product_sum", channel_probs=probs[:N])
+    z = live.decode_batch(np.zeros((2, 1), np.uint8), input_vector_type="syndrome")
+    assert not z["bits"].any()
+    g = graph(200)
+    live.append_rows(g.row_ptr, g.col_idx, N + 200, probs[N : N + 200])
+    full = S.TannerGraph.from_csr(201, N + 200, np.concatenate([[0], g.row_ptr]), g.col_idx)  # the empty check stays row 0
+    fresh = bp.bp_decoder(full, max_iter=20, bp_method="product_sum", channel_probs=np.concatenate([probs[:N], probs[N : N + 200]]))
+    synd = np.concatenate([np.zeros((5, 1), np.uint8), msg[:5, N : N + 200]], axis=1)
+    for nb in (1, 5):
+        _same(live.decode_batch(synd[:nb], want_llr=True, input_vector_type="syndrome"),
+              fresh.decode_batch(synd[:nb], want_llr=True, input_vector_type="syndrome"), ("from empty", nb))
+    fresh.close()
+    live.close()
+
+    # (ii) append with asynchronous decodes still in flight
+    pr = lambda r: np.concatenate([probs[:N], probs[N : N + r]])
+    x = lambda r: np.ascontiguousarray(np.concatenate([msg[:, :N], msg[:, N : N + r]], axis=1))
+    live = bp.bp_decoder(graph(300), max_iter=30, bp_method="min_sum", channel_probs=pr(300))
+    live.configure(path="stream")
+    ref300 = oracle.bp_decode_batch(graph(300), pr(300), x(300), 1, 30, "min_sum", dtype="f32", threads=8, early_exit=False)
+    st = torch.cuda.Stream()
+    with torch.cuda.stream(st):
+        d_in = torch.from_numpy(x(300)).cuda()
+        outs = [torch.zeros((130, N + 300), dtype=torch.uint8, device="cuda") for _ in range(3)]
+        for o in outs:
+            live.decode_batch_device(d_in.data_ptr(), lib.IN_RECEIVED, 130, o.data_ptr(), early_exit=False, stream=st.cuda_stream,
+                                     asynchronous=True)
+    rp, ci = _rows_csr(graph(400), 300, 400)
+    live.append_rows(rp, ci, N + 400, probs[N + 300 : N + 400])  # no synchronisation since the enqueues
+    after = live.decode_batch(x(400), early_exit=False)
+    st.synchronize()
+    for o in outs:
+        assert np.array_equal(o.cpu().numpy(), ref300["bits"])
+    ref400 = oracle.bp_decode_batch(H, probs, msg, 1, 30, "min_sum", dtype="f32", threads=8, early_exit=False)
+    assert np.array_equal(after["bits"], ref400["bits"])
+    live.close()
