@@ -13,7 +13,7 @@ import os
 import numpy as np
 import pytest
 
-from helpers import ORACLE_METHOD, S, compare, hqc_instance
+from helpers import ORACLE_METHOD, S, check_reference_form, compare, hqc_instance
 
 pytestmark = pytest.mark.gpu
 bp = importlib.import_module("sca-ldpc_amd.bp")
@@ -120,7 +120,10 @@ def test_ragged_appends_on_every_kernel_family(oracle, method, path, monkeypatch
                 _same(a, b, (r, nb, early))
         fresh.close()
     ref = oracle.bp_decode_batch(H, probs, msg, 1, 25, ORACLE_METHOD[method], dtype="f32", threads=8)
-    compare(live.decode_batch(msg, early_exit=True, want_llr=True), ref, method)
+    final = live.decode_batch(msg, early_exit=True, want_llr=True)
+    compare(final, ref, method)
+    if method == "product_sum":
+        check_reference_form(oracle, final, H, probs, msg, 1, 25, True)
     live.close()
 
 
@@ -164,7 +167,9 @@ def test_general_growth_new_columns_old_columns_isolated_columns(oracle):
             fresh.close()
     ref = oracle.bp_decode_batch(G, probs, synd, 0, 20, "tanh_complement", dtype="f32", threads=8)
     live.configure(path="stream")
-    compare(live.decode_batch(synd, early_exit=True, want_llr=True), ref, "product_sum")
+    final = live.decode_batch(synd, early_exit=True, want_llr=True)
+    compare(final, ref, "product_sum")
+    check_reference_form(oracle, final, G, probs, synd, 0, 20, True)
     live.close()
 
 

@@ -286,6 +286,8 @@ def test_straggler_compaction_is_invisible(oracle, method, monkeypatch, decode_p
         assert np.array_equal(a[k], b[k]), k
     ref = oracle.bp_decode_batch(H, probs, msg, 1, 60, ORACLE_METHOD[method], dtype="f32", threads=8)
     compare(a, ref, method)
+    if method == "product_sum":
+        check_reference_form(oracle, a, H, probs, msg, 1, 60, True)
     # the Monte-Carlo entry point goes through the same core
     dec.configure(compact_after=-1)
     r1 = dec.mc_hqc_run(500, omega=6, eps=0.03, seed=5)
@@ -350,6 +352,9 @@ def test_row_parallel_path_is_taken_and_agrees_with_tiles(oracle, method, monkey
     ref = oracle.bp_decode_batch(H, probs, msg[:64], 1, 30, ORACLE_METHOD[method], dtype="f32", threads=8,
                                  early_exit=False)
     compare(out["edge"], ref, method)  # nb = 64, received words, fixed iterations
+    if method == "product_sum":
+        with np.errstate(divide="ignore"):
+            check_reference_form(oracle, out["edge"], H, probs, msg[:64], 1, 30, False)
     # the library's own choice: a handful of codewords per call
     monkeypatch.delenv("SCALDPC_PATH", raising=False)
     dec = bp.bp_decoder(H, max_iter=30, bp_method=method, channel_probs=probs)
@@ -380,6 +385,7 @@ def test_compact_pass_hands_few_stragglers_to_row_parallel_kernels(oracle, monke
         assert np.array_equal(a[k], b[k]), k
     ref = oracle.bp_decode_batch(H, probs, msg, 1, 60, ORACLE_METHOD["product_sum"], dtype="f32", threads=8)
     compare(a, ref, "product_sum")
+    check_reference_form(oracle, a, H, probs, msg, 1, 60, True)
 
 
 def test_decoder_per_decode_pattern_and_block_cache(oracle, monkeypatch, decode_path):
@@ -400,6 +406,7 @@ def test_decoder_per_decode_pattern_and_block_cache(oracle, monkeypatch, decode_
         dec.close()
         ref = oracle.bp_decode_batch(H, probs, msg, 1, 40, ORACLE_METHOD["product_sum"], dtype="f32", threads=4)
         compare(got, ref, "product_sum")
+        check_reference_form(oracle, got, H, probs, msg, 1, 40, True, threads=4)
         outs.append((R, got))
         if rep == 2:
             lib.trim()
