@@ -71,6 +71,7 @@ struct Knobs {
     int compact_after = -1;   // -1 = default (4); 0 = no compact pass
     int minsum_loop = 0;      // loop form of the min-sum check kernel (A/B knob)
     int var_order = -1;       // k_var launch order: bit 0 = inside a degree by first edge id, bit 1 = heaviest columns first; -1 = auto
+    int fuse_finalize = 1;    // tile early-exit loop: convergence test and latch in one launch (k_parity_fin); 0 = k_parity + k_finalize
     int speculate = 1;        // early-exit tile groups: stop at the hand-over point without polling once two groups in a row did (0 = always poll)
     int var_form = 1;         // k_var: 0 = ids fetched edge by edge, 1 = all ids up front as wide scalar loads (default)
 };
@@ -204,6 +205,7 @@ bool set_knob(Knobs &k, const char *key, const char *val)
     else if (!strcmp(key, "var_order")) k.var_order = (int)x;
     else if (!strcmp(key, "var_form")) k.var_form = (int)x;
     else if (!strcmp(key, "speculate")) k.speculate = (int)x != 0;
+    else if (!strcmp(key, "fuse_finalize")) k.fuse_finalize = (int)x != 0;
     else return false;
     return true;
 }
@@ -213,7 +215,7 @@ void knobs_from_env(Knobs &k)
     static const char *const names[][2] = {{"SCALDPC_PATH", "path"}, {"SCALDPC_SPLIT", "split"},
                                            {"SCALDPC_GROUP_MB", "group_mb"}, {"SCALDPC_EL_MAX", "el_max"},
                                            {"SCALDPC_EL_FUSE", "el_fuse"}, {"SCALDPC_COMPACT_AFTER", "compact_after"},
-                                           {"SCALDPC_VAR_ORDER", "var_order"}, {"SCALDPC_VAR_FORM", "var_form"}, {"SCALDPC_SPECULATE", "speculate"}};
+                                           {"SCALDPC_VAR_ORDER", "var_order"}, {"SCALDPC_VAR_FORM", "var_form"}, {"SCALDPC_SPECULATE", "speculate"}, {"SCALDPC_FUSE_FINALIZE", "fuse_finalize"}};
     for (auto &nm : names)
         if (const char *e = getenv(nm[0])) (void)set_knob(k, nm[1], e);
     if (getenv("SCALDPC_MINSUM_LOOP")) k.minsum_loop = 1;  // presence switches it on, as before
@@ -829,6 +831,8 @@ int iterate_tiles(scaldpc_bp *h, const TileState &st, int g0, int g, int max_ite
         LAUNCH_CHECK();
     }
     if (early) SC_HIP(hipMemsetAsync(h->d_remaining, 0, sizeof(int) * ((size_t)max_iter + 2), s));
+    if (h->kn.fuse_finalize)  // k_parity_fin: accumulator and block counter of every tile of the group start at zero
+        SC_HIP(hipMemsetAsync(st.unsat + (size_t)g0 * pw, 0, sizeof(u64) * (size_t)g * pw, s));
     if (nl > 1) {  // fork: the other lanes start after everything enqueued on `s` so far
         SC_HIP(hipEventRecord(h->ev_join[0], s));
         for (int k = 1; k < nl; k++) SC_HIP(hipStreamWaitEvent(lane[k], h->ev_join[0], 0));
@@ -857,7 +861,13 @@ int iterate_tiles(scaldpc_bp *h, const TileState &st, int g0, int g, int max_ite
             const int ta = g0 + t0[k];
             SC_TRY(launch_var(h, gs[k], st.post ? st.post + (size_t)ta * h->n * TW : nullptr, st.hard + (size_t)ta * h->n,
                               st.done + ta, skip, (early || last) ? 1 : 0, lane[k], t0[k]));
-            if (early || last) {
+            if ((early || last) && h->kn.fuse_finalize) {  // convergence test + latch, one launch
+                hipLaunchKernelGGL(k_parity_fin, dim3((h->m + 4 * ROWS_PER_WAVE - 1) / (4 * ROWS_PER_WAVE), gs[k]), dim3(256), 0,
+                                   lane[k], h->d_row_ptr, h->d_col_idx, st.hard + (size_t)ta * h->n, h->m, h->n,
+                                   st.synd + (size_t)ta * h->m, st.unsat + (size_t)ta * pw, pw, it, early ? 1 : 0, st.done + ta,
+                                   st.conv + ta, st.iters + (size_t)ta * TW, h->d_remaining + it);
+                LAUNCH_CHECK();
+            } else if (early || last) {
                 hipLaunchKernelGGL(k_parity<true>, dim3((h->m + 4 * ROWS_PER_WAVE - 1) / (4 * ROWS_PER_WAVE), gs[k]), dim3(256),
                                    0, lane[k], h->d_row_ptr, h->d_col_idx, st.hard + (size_t)ta * h->n, h->m, h->n,
                                    const_cast<u64 *>(st.synd + (size_t)ta * h->m), st.unsat + (size_t)ta * pw,

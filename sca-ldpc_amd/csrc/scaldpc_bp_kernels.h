@@ -261,6 +261,97 @@ __global__ __launch_bounds__(64) void k_finalize(int it, int latch, u64 *__restr
     }
 }
 
+// k_parity<true> and k_finalize in ONE launch (the 64-codeword-tile early-exit loop: four launches per
+// iteration and lane become three; the finalize kernel -- a wave per tile -- was 8.5 % of the GPU time of the
+// config-5 sweep, nearly all of it waiting for a slot and for three dependent memory round trips on a chip
+// the other lane keeps saturated).  Every block ORs its rows' mismatches into the tile's accumulator word
+// with ONE device-scope atomic, then takes a ticket from the tile's block counter; the block that draws the
+// last ticket knows every other block's OR has been performed (each waited for its own before it took its
+// ticket) and latches the tile exactly as k_finalize does, then puts both words back to zero for the next
+// launch.  Only atomics carry data between blocks -- performed at the device's coherence point, whatever
+// XCD the blocks run on -- so no cache write-back or invalidate is involved.
+//   unsat: [tile][pw] words, pw >= 4; word 0 = accumulator, word 1 = block counter; zero on entry and exit.
+// grid (ceil(m / (4*ROWS_PER_WAVE)), G), block 256.
+__global__ __launch_bounds__(256) void k_parity_fin(const int *__restrict__ row_ptr, const int *__restrict__ col_idx,
+                                                    const u64 *__restrict__ bits, int m, int n,
+                                                    const u64 *__restrict__ synd, u64 *unsat, int pw, int it, int latch,
+                                                    u64 *done, u64 *conv, int *__restrict__ iters,
+                                                    int *__restrict__ remaining)
+{
+    __shared__ u64 sbad[4];
+    __shared__ int s_last;
+    const int lane = threadIdx.x & 63;
+    const int t = blockIdx.y;
+    const u64 dw = done[t];
+    if (dw == ~0ull) return;  // whole tile frozen (uniform over the launch row: no ticket is drawn for it)
+    const int wv = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int r0 = wv * ROWS_PER_WAVE;
+    const u64 *bt = bits + (size_t)t * n;
+    u64 bad = 0;
+    constexpr int IL = 4;
+    const int rend = min(r0 + ROWS_PER_WAVE, m);
+    for (int rb = r0; rb < rend; rb += IL) {
+        u64 a[IL];
+        int ea[IL], eb[IL];
+#pragma unroll
+        for (int i = 0; i < IL; i++) {
+            const int r = min(rb + i, rend - 1);
+            ea[i] = rfl(row_ptr[r]) + lane;
+            eb[i] = rb + i < rend ? rfl(row_ptr[r + 1]) : 0;
+        }
+#pragma unroll
+        for (int i = 0; i < IL; i++) a[i] = ea[i] < eb[i] ? bt[col_idx[ea[i]]] : 0ull;
+#pragma unroll
+        for (int i = 0; i < IL; i++)
+            for (int e = ea[i] + 64; e < eb[i]; e += 64) a[i] ^= bt[col_idx[e]];
+#pragma unroll
+        for (int i = 0; i < IL; i++) {
+            const int r = rb + i;
+            if (r >= rend) break;
+            u64 x = a[i];
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) x ^= __shfl_xor(x, off);
+            bad |= x ^ synd[(size_t)t * m + r];
+        }
+    }
+    if (lane == 0) sbad[threadIdx.x >> 6] = bad;
+    __syncthreads();
+    u64 *acc = unsat + (size_t)t * pw;
+    if (threadIdx.x == 0) {
+        const u64 b = sbad[0] | sbad[1] | sbad[2] | sbad[3];
+        if (b) {
+            const u64 old = atomicOr(acc, b);
+            asm volatile("s_waitcnt vmcnt(0)" ::"v"((unsigned)old) : "memory");  // the OR is performed before the ticket is drawn
+        }
+        const unsigned tk = atomicAdd((unsigned *)(acc + 1), 1u);
+        s_last = tk == gridDim.x - 1;
+    }
+    __syncthreads();
+    if (!s_last || threadIdx.x >= 64) return;
+    // the tile's last block: latch (k_finalize), and leave the two words zero for the next launch
+    const int c = threadIdx.x;
+    unsigned lo = 0, hi = 0;
+    if (c == 0) {
+        const u64 uw0 = atomicExch(acc, 0ull);
+        (void)atomicExch((unsigned *)(acc + 1), 0u);
+        lo = (unsigned)uw0;
+        hi = (unsigned)(uw0 >> 32);
+    }
+    const u64 uw = ((u64)(unsigned)rfl((int)hi) << 32) | (unsigned)rfl((int)lo);
+    const u64 newly = ~dw & ~uw;
+    if (latch) {
+        if ((newly >> c) & 1) iters[(long)t * TW + c] = it;
+        if (c == 0) {
+            done[t] = dw | newly;
+            conv[t] |= newly;
+            const int rem = __popcll(~(dw | newly));
+            if (rem) atomicAdd(remaining, rem);
+        }
+    } else if (c == 0) {
+        conv[t] = newly;  // dw = padding here
+    }
+}
+
 // ---------------------------------------------------------------------------
 // K1  initial bit-to-check messages: msg[tile][e][:] = LLR prior of the edge's column.
 // grid (ceil(E/4), G), block 256 = 4 waves, wave = one 256 B edge row.

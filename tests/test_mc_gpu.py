@@ -70,7 +70,10 @@ def test_config5_sweep_sheds_stragglers_twice(monkeypatch):
     dec.configure(speculate=0)  # every group polls at the hand-over point (instead of stopping there unseen after two that did)
     c = dec.mc_hqc_run(8192, omega=omega, eps=0.05, seed=7)
     assert np.array_equal(a["success"], c["success"]) and np.array_equal(a["iters"], c["iters"])
-    dec.configure(compact_after=0)
+    dec.configure(speculate=1, fuse_finalize=0)  # convergence test and latch as two launches instead of one
+    e = dec.mc_hqc_run(8192, omega=omega, eps=0.05, seed=7)
+    assert np.array_equal(a["success"], e["success"]) and np.array_equal(a["iters"], e["iters"])
+    dec.configure(fuse_finalize=1, compact_after=0)
     b = dec.mc_hqc_run(8192, omega=omega, eps=0.05, seed=7)
     assert dec.last_stats()["levels"] == 0
     dec.close()
