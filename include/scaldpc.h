@@ -181,7 +181,9 @@ int scaldpc_bp_last_stats(scaldpc_bp *h, int64_t *out);
  *                   (default), 0 = one scalar load per edge
  *   "speculate"     1 (default) = an early-exit tile group stops at the hand-over point without polling the
  *                   device once two groups in a row handed a small remainder to the compact pass there,
- *                   0 = every group polls.  Results never depend on any of these. */
+ *                   0 = every group polls
+ *   "fuse_finalize" 1 (default) = convergence test and latch of the tile early-exit loop in one launch,
+ *                   0 = two launches.  Results never depend on any of these. */
 int scaldpc_bp_configure(scaldpc_bp *h, const char *key, const char *value);
 /* Where a handle lives, out[4]: the device it was created on; the device (hipPointerGetAttributes)
  * of its graph allocation, of its message workspace and of its state planes (-1 = not allocated yet).
