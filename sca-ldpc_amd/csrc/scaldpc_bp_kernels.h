@@ -429,48 +429,21 @@ __device__ __forceinline__ void check_minsum_row(float *p, unsigned par, float a
     float x[DEG];
 #pragma unroll
     for (int k = 0; k < DEG; k++) x[k] = FIRST ? prior[rfl(cidx[k])] : p[(size_t)k * TW];
-    // (min1, min2, arg-min) of |x| by NC interleaved running scans, merged at the end: the one scan of the
-    // reference is a chain of DEG dependent compare/select steps -- 65 % of this kernel's wave cycles were
-    // issue stalls on it (profiles/r02/sq_counters_hqc128_minsum.json) -- and its results do not depend on
-    // the order: min1 / min2 are exact minima, and the arg-min only matters when min1 < min2, where it is unique
-    // (if the two smallest are equal every edge gets the same magnitude whichever index is excluded).
-    constexpr int NC = DEG >= 16 ? 4 : (DEG >= 6 ? 2 : 1);
-    float m1[NC], m2[NC];
-    int ix[NC];
-#pragma unroll
-    for (int c = 0; c < NC; c++) {
-        m1[c] = FLT_MAX;
-        m2[c] = FLT_MAX;
-        ix[c] = 0;
-    }
+    float m1 = FLT_MAX, m2 = FLT_MAX;
+    int ix = 0;
 #pragma unroll
     for (int k = 0; k < DEG; k++) {
-        constexpr int dummy = 0;
-        (void)dummy;
-        const int c = k % NC;
         const float a = fabsf(x[k]);
         par ^= (unsigned)(x[k] <= 0.0f);
-        const bool lt = a < m1[c];
-        m2[c] = lt ? m1[c] : ((a < m2[c]) ? a : m2[c]);
-        ix[c] = lt ? k : ix[c];
-        m1[c] = lt ? a : m1[c];
+        const bool lt = a < m1;
+        m2 = lt ? m1 : ((a < m2) ? a : m2);
+        ix = lt ? k : ix;
+        m1 = lt ? a : m1;
     }
-#pragma unroll
-    for (int w = 1; w < NC; w *= 2)
-#pragma unroll
-        for (int c = 0; c + w < NC; c += 2 * w) {
-            const float a1 = m1[c], b1 = m1[c + w];
-            const bool lt = b1 < a1;
-            const float hi = lt ? a1 : b1;  // the larger of the two minima
-            float s = m2[c] < m2[c + w] ? m2[c] : m2[c + w];
-            m2[c] = hi < s ? hi : s;
-            ix[c] = lt ? ix[c + w] : ix[c];
-            m1[c] = lt ? b1 : a1;
-        }
     const float nalpha = -alpha;
 #pragma unroll
     for (int k = 0; k < DEG; k++)
-        p[(size_t)k * TW] = ((k == ix[0]) ? m2[0] : m1[0]) * ((par ^ (unsigned)(x[k] <= 0.0f)) ? nalpha : alpha);
+        p[(size_t)k * TW] = ((k == ix) ? m2 : m1) * ((par ^ (unsigned)(x[k] <= 0.0f)) ? nalpha : alpha);
 }
 
 template <int CAP, bool FIRST>
