@@ -88,6 +88,11 @@ int scaldpc_set_device(int device);
  * times the decode.  scaldpc_trim() returns the parked blocks to the driver;
  * SCALDPC_NO_CACHE=1 in the environment disables parking. */
 int scaldpc_trim(void);
+/* Leak accounting (tests, profiles/microbench/leak_check.py): blocks the library's allocator has handed
+ * out and that a live handle still owns.  out[6] = { device blocks, device bytes, pinned-host blocks,
+ * pinned-host bytes, parked (idle) blocks, parked bytes }.  A create / decode / destroy cycle must leave
+ * out[0..3] where it found them -- the reference builds a decoder per decode (simulate/hqc.py:694-708). */
+int scaldpc_debug_live_blocks(int64_t *out);
 
 /* ------------------------------------------------------------------ binary BP */
 typedef struct scaldpc_bp scaldpc_bp;

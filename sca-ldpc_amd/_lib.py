@@ -43,6 +43,8 @@ def _declare(lib):
     lib.scaldpc_set_device.argtypes = [C.c_int]
     lib.scaldpc_trim.argtypes = []
     lib.scaldpc_trim.restype = C.c_int
+    lib.scaldpc_debug_live_blocks.argtypes = [p(C.c_int64)]
+    lib.scaldpc_debug_live_blocks.restype = C.c_int
     lib.scaldpc_bp_create.argtypes = [C.c_int32, C.c_int32, C.c_int64, vp, vp, p(vp)]
     lib.scaldpc_bp_set_channel_probs.argtypes = [vp, vp]
     lib.scaldpc_bp_decode_batch.argtypes = [
@@ -132,6 +134,14 @@ def check(rc):
 def trim():
     """Return the device / pinned blocks parked by destroyed decoders to the driver."""
     check(load().scaldpc_trim())
+
+
+def live_blocks():
+    """Allocator accounting: blocks live handles own (device / pinned host) and blocks parked for reuse."""
+    out = (C.c_int64 * 6)()
+    check(load().scaldpc_debug_live_blocks(out))
+    keys = ("device_blocks", "device_bytes", "pinned_blocks", "pinned_bytes", "idle_blocks", "idle_bytes")
+    return dict(zip(keys, (int(v) for v in out)))
 
 
 def ptr(a):

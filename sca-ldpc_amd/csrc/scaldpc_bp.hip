@@ -314,8 +314,6 @@ int ensure_workspace(scaldpc_bp *h, int T, int G, bool want_post, int max_iter)
     if (max_iter + 2 > h->cap_remaining) {
         dev_free(h->d_remaining);
         cached_free(h->h_remaining);
-    cached_free(h->h_io);
-    dev_free(h->d_out_all);
         h->h_remaining = nullptr;
         h->cap_remaining = 0;
         SC_TRY(dev_alloc(&h->d_remaining, (size_t)max_iter + 2));
@@ -2088,6 +2086,8 @@ void scaldpc_bp_destroy(scaldpc_bp *h)
     dev_free(h->d_emsg); dev_free(h->d_el_unsat);
     dev_free(h->d_thr); dev_free(h->d_mc); dev_free(h->d_diff); dev_free(h->d_ylist); dev_free(h->d_succ);
     cached_free(h->h_remaining);
+    cached_free(h->h_io);  // the small-call staging pair (decode_batch's fused host path)
+    dev_free(h->d_out_all);
     if (h->own_stream) stream_release(h->own_stream, h->device);
     for (int k = 0; k < 4; k++) {
         if (h->aux_stream[k]) stream_release(h->aux_stream[k], h->device);

@@ -14,7 +14,7 @@
 #include <stdint.h>
 #include <string.h>
 
-#if defined(__HIPCC__) || defined(__CUDACC__)
+#if defined(__HIPCC__)
 #define SCALDPC_HD __host__ __device__
 #else
 #define SCALDPC_HD

@@ -202,6 +202,22 @@ extern "C" {
 const char *scaldpc_last_error(void) { return last_error().c_str(); }
 int scaldpc_version(void) { return SCALDPC_VERSION; }
 
+int scaldpc_debug_live_blocks(int64_t *out)
+{
+    if (!out) return fail(SCALDPC_EINVAL, "out is NULL");
+    BlockCache &bc = block_cache();
+    std::lock_guard<std::mutex> lk(bc.mu);
+    for (int i = 0; i < 6; i++) out[i] = 0;
+    for (auto &kv : bc.live) {
+        const int k = kv.second.device < 0 ? 2 : 0;
+        out[k]++;
+        out[k + 1] += (int64_t)kv.second.bytes;
+    }
+    out[4] = (int64_t)bc.idle.size();
+    out[5] = (int64_t)bc.idle_bytes;
+    return 0;
+}
+
 int scaldpc_device_count(int *count)
 {
     if (!count) return fail(SCALDPC_EINVAL, "count is NULL");
