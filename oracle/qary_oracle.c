@@ -19,7 +19,10 @@
  * decoder.rs:744-768 (into_llr exact values), :771-799 (6x3, Q=15, 10 it),
  * :819-854 (150x450 + benches/parity_check_150_450.txt), decode.py:192-209.
  * decoder_special.rs has no live test (its tests are commented out, :691-746):
- * oracle_qary_special is "parity unpinned".
+ * oracle_qary_special is "parity unpinned" by the reference.  ...pinned on cycle-free
+ * graphs by tests/test_exact_inference*.py: on tree-shaped [H' | +-I] (B = 2, BSUM = 12)
+ * its decision, and the HIP path's, is the enumerated minimum-cost valid assignment;
+ * the same holds for oracle_qary_min_sum on random +-1 trees with B = 1, 2.
  */
 #include <math.h>
 #include <stdint.h>

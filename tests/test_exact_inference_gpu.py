@@ -1,8 +1,8 @@
 """The HIP path against exact inference on cycle-free graphs (tests/exact.py) -- no oracle in between.
 
 Same answer key and cases as tests/test_exact_inference.py: BP is exact on trees, so posterior LLRs
-of the tanh rule are the true marginals (held to the product path's stated fp32 tolerance,
-|dL| <= 1e-4 * max(1, |L|)), min-sum posteriors are the true min-cost differences (fp32 rounding of a
+of the tanh rule are the true marginals (held to 2e-5 * (1 + |L|): five times inside the product
+path's stated fp32 tolerance), min-sum posteriors are the true min-cost differences (fp32 rounding of a
 handful of additions), hard decisions are exact, and the q-ary decoders return the enumerated optimum.
 Every kernel family is held to the key: LDS-resident single launch, 64-codeword tiles, row-parallel;
 for the q-ary decoders the lane-per-codeword, wave-per-check, unrolled and tree-walk forms.
@@ -20,7 +20,9 @@ S = importlib.import_module("sca-ldpc_amd")
 bp = importlib.import_module("sca-ldpc_amd.bp")
 qary = importlib.import_module("sca-ldpc_amd.qary")
 
-TOL = {"product_sum": (1e-4, 1e-4, "sp"), "min_sum": (4e-6, 4e-6, "ms")}
+# tanh rule: the product path's stated fp32 tolerance is 1e-4 * max(1, |L|); against the exact marginals it
+# measures 1.5e-6 on these cases (all three kernel families), so it is held to 2e-5 here
+TOL = {"product_sum": (2e-5, 2e-5, "sp"), "min_sum": (4e-6, 4e-6, "ms")}
 
 
 def hip_decode(H, probs, synds, method, iters, path):
