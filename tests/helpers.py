@@ -122,20 +122,36 @@ def compare_with_reference_form(got, ref64, tol=1e-3, clamp=30.0):
     assert np.array_equal(got["bits"][decided], ref64["bits"][decided])
 
 
-def check_reference_form(oracle, got, H, probs, x, kind, max_iter, early, min_fraction=0.0, threads=8):
+def reference_floor(ref, share=0.8):
+    """Floor for `check_reference_form`: `share` of the codewords the f32 oracle converged on must also
+    qualify for the float64 comparison -- so the check cannot pass by comparing nothing, yet a test whose
+    trials mostly do not converge (by design) is not asked for more than exists."""
+    return share * float(np.asarray(ref["converged"]).astype(bool).mean())
+
+
+COMPARED = {}  # call-site label -> [codewords compared with the float64 reference form, codewords seen]
+
+
+def check_reference_form(oracle, got, H, probs, x, kind, max_iter, early, *, min_fraction, threads=8, tol=1e-3, label=None):
     """The independent check of every product-sum parity test: the HIP result against the float64
     probability-ratio recursion of the reference's package (oracle method 0) -- a different
     formulation in a different precision, so nothing here can mirror the device.  Compared on the
     codewords whose float64 decode settles (converged, and the same iteration count as the device):
     a trial that never converges wanders chaotically and float32 and float64 part ways on it by
-    construction.  `min_fraction` keeps the check from going vacuous.  Returns the fraction compared."""
+    construction.  `min_fraction` (REQUIRED: every call site states its floor, see `reference_floor`)
+    keeps the check from going vacuous; `label` adds the counts to COMPARED so that a property test can
+    assert, over its whole run, that something was compared.  Returns the fraction compared."""
     with np.errstate(divide="ignore", invalid="ignore"):
         ref64 = oracle.bp_decode_batch(H, probs, x, kind, max_iter, "product_sum", dtype="f64", threads=threads,
                                        early_exit=early)
     keep = ref64["converged"].astype(bool) & (got["iters"] == ref64["iters"])
     frac = float(keep.mean())
-    assert frac >= min_fraction, f"only {frac:.2f} of the codewords qualify for the float64 comparison"
+    if label is not None:
+        c = COMPARED.setdefault(label, [0, 0])
+        c[0] += int(keep.sum())
+        c[1] += int(keep.size)
+    assert frac >= min_fraction, f"only {frac:.3f} of the codewords qualify for the float64 comparison (floor {min_fraction:.3f})"
     if keep.any():
         compare_with_reference_form({k: (v[keep] if v is not None else None) for k, v in got.items()},
-                                    {k: (v[keep] if v is not None else None) for k, v in ref64.items()})
+                                    {k: (v[keep] if v is not None else None) for k, v in ref64.items()}, tol=tol)
     return frac

@@ -9,7 +9,7 @@ import pytest
 from hypothesis import HealthCheck, given, settings
 from hypothesis import strategies as st
 
-from helpers import ORACLE_METHOD, S, compare
+from helpers import COMPARED, ORACLE_METHOD, S, check_reference_form, compare, reference_floor
 
 pytestmark = pytest.mark.gpu
 bp = importlib.import_module("sca-ldpc_amd.bp")
@@ -82,8 +82,15 @@ def test_random_instances(oracle, m, n, density, batch, method, received, early,
     # scales with what the oracle itself moves when the same operation order runs in double: the
     # device may deviate from the f32 oracle by 20x that, and never gets less than the fixed fp32
     # tolerance the LDPC-shaped tests use.
-    compare(got, ref, method, widened_tol=_own_sensitivity(oracle, g, probs, x, 1 if received else 0, max_iter, method, early, ref),
-            tie_codewords=1 + batch // 64)
+    tol = _own_sensitivity(oracle, g, probs, x, 1 if received else 0, max_iter, method, early, ref)
+    compare(got, ref, method, widened_tol=tol, tie_codewords=1 + batch // 64)
+    if method == "product_sum":
+        # ... and the float64 reference form (oracle method 0), on the codewords that settle.  No per-example floor on
+        # these odd little graphs (an example may have none); the run as a whole must have compared something,
+        # see test_the_reference_form_checks_compared_something.
+        with np.errstate(divide="ignore", invalid="ignore"):
+            check_reference_form(oracle, got, g, probs, x, 1 if received else 0, max_iter, early, min_fraction=0.0,
+                                 threads=4, tol=max(1e-3, tol), label="tiny")
 
 
 @settings(max_examples=int(os.environ.get("SCALDPC_PROPERTY_EXAMPLES", "24")), deadline=None, derandomize=True,
@@ -131,5 +138,20 @@ def test_random_hqc_shaped_instances(oracle, N, W, rfrac, omega, eps, batch, met
     finally:
         for k in keys:
             os.environ.pop(k, None)
-    compare(got, ref, method, widened_tol=_own_sensitivity(oracle, H, probs, msg, 1, max_iter, method, early, ref),
-            tie_codewords=1 + batch // 64)
+    tol = _own_sensitivity(oracle, H, probs, msg, 1, max_iter, method, early, ref)
+    compare(got, ref, method, widened_tol=tol, tie_codewords=1 + batch // 64)
+    if method == "product_sum":
+        # the float64 reference form must cover at least 60 % of what the f32 oracle converged on (ties of the decision
+        # rule may move a codeword's iteration count by one between float32 and float64, hence not 100 %)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            check_reference_form(oracle, got, H, probs, msg, 1, max_iter, early, min_fraction=reference_floor(ref, 0.6),
+                                 threads=8, tol=max(1e-3, tol), label="hqc")
+
+
+def test_the_reference_form_checks_compared_something():
+    """Runs after the two property tests above (definition order): over the whole hypothesis run each of them must
+    have compared codewords against the float64 reference form -- a per-example floor of 0 is not a vacuous pass."""
+    for label in ("tiny", "hqc"):
+        compared, seen = COMPARED.get(label, (0, 0))
+        assert seen > 0 and compared > 0, (label, compared, seen)
+        print(f"float64 reference form, {label}: {compared} of {seen} codewords compared")
