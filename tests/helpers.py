@@ -132,7 +132,8 @@ def reference_floor(ref, share=0.8):
 COMPARED = {}  # call-site label -> [codewords compared with the float64 reference form, codewords seen]
 
 
-def check_reference_form(oracle, got, H, probs, x, kind, max_iter, early, *, min_fraction, threads=8, tol=1e-3, label=None):
+def check_reference_form(oracle, got, H, probs, x, kind, max_iter, early, *, min_fraction, threads=8, tol=1e-3, label=None,
+                         same_order64=None):
     """The independent check of every product-sum parity test: the HIP result against the float64
     probability-ratio recursion of the reference's package (oracle method 0) -- a different
     formulation in a different precision, so nothing here can mirror the device.  Compared on the
@@ -140,11 +141,21 @@ def check_reference_form(oracle, got, H, probs, x, kind, max_iter, early, *, min
     a trial that never converges wanders chaotically and float32 and float64 part ways on it by
     construction.  `min_fraction` (REQUIRED: every call site states its floor, see `reference_floor`)
     keeps the check from going vacuous; `label` adds the counts to COMPARED so that a property test can
-    assert, over its whole run, that something was compared.  Returns the fraction compared."""
+    assert, over its whole run, that something was compared.  `same_order64` (the tiny-dense-graph property test only):
+    the oracle's float64 LLR-domain result (method 3).  On a small graph dense with short cycles, loopy BP saturates
+    within a few iterations and CONTRADICTING certainties meet (+inf from one check, -inf from another, or a degree-1
+    check against a p = 0 prior): the LLR forms make inf - inf = NaN or keep the infinity, the package's ratio form
+    multiplies 0 * inf and resets the NaN to 1.0 and carries on with a finite number -- two
+    formulations of the ORACLE part ways there (measured: 8.06 against inf, both float64), so codewords on which
+    methods 0 and 3 disagree about where the non-finite posteriors sit are outside what a cross-formulation comparison
+    can say anything about.  Returns the fraction compared."""
     with np.errstate(divide="ignore", invalid="ignore"):
         ref64 = oracle.bp_decode_batch(H, probs, x, kind, max_iter, "product_sum", dtype="f64", threads=threads,
                                        early_exit=early)
     keep = ref64["converged"].astype(bool) & (got["iters"] == ref64["iters"])
+    if same_order64 is not None:
+        keep &= (np.isfinite(ref64["llr"]) == np.isfinite(same_order64["llr"])).all(axis=1)
+        keep &= (np.isnan(ref64["llr"]) == np.isnan(same_order64["llr"])).all(axis=1)
     frac = float(keep.mean())
     if label is not None:
         c = COMPARED.setdefault(label, [0, 0])

@@ -18,7 +18,7 @@ bp = importlib.import_module("sca-ldpc_amd.bp")
 def _own_sensitivity(oracle, g, probs, x, kind, max_iter, method, early, ref):
     """20x the largest relative move of the oracle's posteriors between float32 and float64 (same
     operation order), never below the fixed fp32 tolerance 2e-4."""
-    tol = 2e-4
+    tol, ref64 = 2e-4, None
     if method == "product_sum":
         with np.errstate(divide="ignore", invalid="ignore"):
             ref64 = oracle.bp_decode_batch(g, probs, x, kind, max_iter, ORACLE_METHOD[method], dtype="f64", threads=8,
@@ -28,7 +28,7 @@ def _own_sensitivity(oracle, g, probs, x, kind, max_iter, method, early, ref):
         own = own[np.isfinite(own)]
         if own.size:
             tol = max(tol, 20.0 * float(own.max()))
-    return tol
+    return tol, ref64
 
 
 @settings(max_examples=int(os.environ.get("SCALDPC_PROPERTY_EXAMPLES", "60")), deadline=None, derandomize=True,
@@ -82,7 +82,7 @@ def test_random_instances(oracle, m, n, density, batch, method, received, early,
     # scales with what the oracle itself moves when the same operation order runs in double: the
     # device may deviate from the f32 oracle by 20x that, and never gets less than the fixed fp32
     # tolerance the LDPC-shaped tests use.
-    tol = _own_sensitivity(oracle, g, probs, x, 1 if received else 0, max_iter, method, early, ref)
+    tol, same64 = _own_sensitivity(oracle, g, probs, x, 1 if received else 0, max_iter, method, early, ref)
     compare(got, ref, method, widened_tol=tol, tie_codewords=1 + batch // 64)
     if method == "product_sum":
         # ... and the float64 reference form (oracle method 0), on the codewords that settle.  No per-example floor on
@@ -90,7 +90,7 @@ def test_random_instances(oracle, m, n, density, batch, method, received, early,
         # see test_the_reference_form_checks_compared_something.
         with np.errstate(divide="ignore", invalid="ignore"):
             check_reference_form(oracle, got, g, probs, x, 1 if received else 0, max_iter, early, min_fraction=0.0,
-                                 threads=4, tol=max(1e-3, tol), label="tiny")
+                                 threads=4, tol=max(1e-3, 2.0 * tol), label="tiny", same_order64=same64)
 
 
 @settings(max_examples=int(os.environ.get("SCALDPC_PROPERTY_EXAMPLES", "24")), deadline=None, derandomize=True,
@@ -138,14 +138,14 @@ def test_random_hqc_shaped_instances(oracle, N, W, rfrac, omega, eps, batch, met
     finally:
         for k in keys:
             os.environ.pop(k, None)
-    tol = _own_sensitivity(oracle, H, probs, msg, 1, max_iter, method, early, ref)
+    tol, _ = _own_sensitivity(oracle, H, probs, msg, 1, max_iter, method, early, ref)
     compare(got, ref, method, widened_tol=tol, tie_codewords=1 + batch // 64)
     if method == "product_sum":
         # the float64 reference form must cover at least 60 % of what the f32 oracle converged on (ties of the decision
         # rule may move a codeword's iteration count by one between float32 and float64, hence not 100 %)
         with np.errstate(divide="ignore", invalid="ignore"):
             check_reference_form(oracle, got, H, probs, msg, 1, max_iter, early, min_fraction=reference_floor(ref, 0.6),
-                                 threads=8, tol=max(1e-3, tol), label="hqc")
+                                 threads=8, tol=max(1e-3, 2.0 * tol), label="hqc")
 
 
 def test_the_reference_form_checks_compared_something():
