@@ -247,6 +247,15 @@ int scaldpc_qary_into_llr(const float *pmf, int64_t rows, int32_t Q, uint32_t fl
  * "tree" = 1 tree-walk check kernel for the Kyber shape (B = 2, six coefficient edges per check) | 0 off
  * (SCALDPC_QARY_NO_TREE). */
 int scaldpc_qary_configure(scaldpc_qary *h, const char *key, const char *value);
+/* Measurement aid for bench.py (the q-ary counterpart of scaldpc_bp_time_kernels): after
+ * scaldpc_qary_configure(h, "timing", "1"), every check-node and variable-node launch of a call is bracketed by
+ * HIP events on the launch stream (off by default -- the product path records nothing).  For the last call:
+ *   ms[0] / ms[1]  total ms of its check / variable launches;  ms[2]  from the first check launch to the last
+ *                  variable launch (the iteration loop, without the probability -> LLR conversion and the copies)
+ *   info[0] iterations run;  info[1] check kernel: 0 k_q_check_unrolled<3,7>, 1 k_q_check_unrolled<5,5>,
+ *           2 k_q_special_check_tree<5,6> (+ wave kernel for other row degrees), 3 k_q_special_check_wave,
+ *           4 k_q_check_wave, 5 k_q_special_check, 6 k_q_check;  info[2] batch;  info[3] largest check degree */
+int scaldpc_qary_last_timing(scaldpc_qary *h, float *ms, int32_t *info);
 
 /* DecoderSpecial: H = [H' | I_R]; first N-R variables over [-B,B], last R over [-BSUM,BSUM]. */
 int scaldpc_qary_special_create(int32_t R, int32_t N, int32_t B, int32_t BSUM, const int8_t *H,

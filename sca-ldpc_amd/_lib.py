@@ -83,6 +83,8 @@ def _declare(lib):
     lib.scaldpc_qary_min_sum_batch.argtypes = [vp, vp, C.c_int32, C.c_uint32, vp, vp]
     lib.scaldpc_qary_configure.argtypes = [vp, C.c_char_p, C.c_char_p]
     lib.scaldpc_qary_configure.restype = C.c_int
+    lib.scaldpc_qary_last_timing.argtypes = [vp, p(C.c_float), p(C.c_int32)]
+    lib.scaldpc_qary_last_timing.restype = C.c_int
     lib.scaldpc_qary_into_llr.argtypes = [vp, C.c_int64, C.c_int32, C.c_uint32, vp, vp]
     lib.scaldpc_qary_into_llr.restype = C.c_int
     lib.scaldpc_qary_destroy.argtypes = [vp]

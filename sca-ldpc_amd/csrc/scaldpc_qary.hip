@@ -775,6 +775,12 @@ struct scaldpc_qary {
     int kn_wave = -1;    // -1: wave-parallel enumeration for batches <= 256 and the special decoder; 0 / 1 force
     int kn_unroll = 1;   // register-resident unrolled enumeration for small alphabets
     int kn_tree = 1;     // special decoder: tree-walk check kernel for the Kyber shape (QB = 5, 6 coefficient edges)
+    // measurement aid (bench.py): with "timing" = 1 every check / variable launch of a call is bracketed by HIP events
+    // on the launch stream; scaldpc_qary_last_timing reads the sums.  Off by default: the product path records nothing.
+    int kn_timing = 0;
+    std::vector<hipEvent_t> tev;
+    float stat_ms_check = 0.f, stat_ms_var = 0.f, stat_ms_call = 0.f;
+    int stat_iters = 0, stat_kernel = -1, stat_batch = 0;
     std::mutex mu;
 };
 
@@ -967,7 +973,20 @@ int qary_run(scaldpc_qary *h, const float *pmf_b, const float *pmf_s, int batch,
     }
     // special decoder, Kyber shape (B = 2, rows of up to 6 coefficient edges + the row-sum edge): tree-walk kernel
     const int tree_nb = (h->special && h->kn_tree && (h->kn_wave != 0) && h->Q == 5 && h->maxdc - 1 == 6 && wave_lds <= 64 * 1024) ? 6 : 0;
+    // which check kernel this call runs (scaldpc_qary_last_timing's info[1])
+    const int kernel_id = !h->E ? -1 : unrolled == 3 ? 0 : unrolled == 5 ? 1 : (h->special && tree_nb) ? 2 : (wave_mode && h->special) ? 3
+                          : wave_mode ? 4 : h->special ? 5 : 6;
+    const bool timing = h->kn_timing != 0;
+    if (timing) {
+        while (h->tev.size() < (size_t)2 * iters + 2) {
+            hipEvent_t e;
+            SC_HIP(hipEventCreate(&e));
+            h->tev.push_back(e);
+        }
+        SC_HIP(hipEventRecord(h->tev[2 * iters + 1], s));  // start of the call's device work is behind us: into_llr + init
+    }
     for (int it = 1; it <= iters; it++) {
+        if (timing) SC_HIP(hipEventRecord(h->tev[2 * (it - 1)], s));
         if (h->E) {
             if (unrolled == 3)
                 hipLaunchKernelGGL((k_q_check_unrolled<3, 7>), dim3(h->R, Bp / 64), dim3(64), 0, s, h->d_row_ptr, h->d_msg, Bp,
@@ -997,11 +1016,13 @@ int qary_run(scaldpc_qary *h, const float *pmf_b, const float *pmf_s, int batch,
                                    h->Q, h->B, Bp, batch, h->maxdc, h->d_err);
             SC_HIP(hipGetLastError());
         }
+        if (timing) SC_HIP(hipEventRecord(h->tev[2 * (it - 1) + 1], s));
         hipLaunchKernelGGL(k_q_var, dim3(h->N, Bp / TB), dim3(TB), (size_t)2 * h->W * TB * 4, s, 0, h->d_col_ptr,
                            h->d_csc_edge, h->d_edge_h, h->d_var_q, h->d_var_off, h->d_llr, h->d_msg, h->W, Bp, batch, h->W,
                            it == iters ? 1 : 0, h->d_hard);
         SC_HIP(hipGetLastError());
     }
+    if (timing) SC_HIP(hipEventRecord(h->tev[2 * iters], s));
     signed char *dout = (signed char *)out;
     if (!dev_io) {
         SC_TRY(growq(&h->d_out, &h->cap_out, (size_t)batch * h->N));
@@ -1015,6 +1036,20 @@ int qary_run(scaldpc_qary *h, const float *pmf_b, const float *pmf_s, int batch,
     SC_HIP(hipMemcpyAsync(&bad, h->d_first_bad, sizeof(u64), hipMemcpyDeviceToHost, s));
     if (!dev_io) SC_HIP(hipMemcpyAsync(out, dout, (size_t)batch * h->N, hipMemcpyDeviceToHost, s));
     SC_HIP(hipStreamSynchronize(s));
+    if (timing) {
+        h->stat_ms_check = h->stat_ms_var = 0.f;
+        for (int it = 0; it < iters; it++) {
+            float a = 0.f, b = 0.f;
+            SC_HIP(hipEventElapsedTime(&a, h->tev[2 * it], h->tev[2 * it + 1]));
+            SC_HIP(hipEventElapsedTime(&b, h->tev[2 * it + 1], h->tev[2 * it + 2]));
+            h->stat_ms_check += a;
+            h->stat_ms_var += b;
+        }
+        SC_HIP(hipEventElapsedTime(&h->stat_ms_call, h->tev[2 * iters + 1], h->tev[2 * iters]));
+        h->stat_iters = iters;
+        h->stat_kernel = kernel_id;
+        h->stat_batch = batch;
+    }
     if (err == QERR_PMF) {
         const int bb = (int)(bad >> 32), vv = (int)((bad & 0x7fffffffull) >> 1) + (((bad >> 31) & 1) ? BV : 0);
         if (bad & 1) return fail(SCALDPC_EPMF, "No maximum probability found (codeword %d, variable %d)", bb, vv);
@@ -1098,8 +1133,25 @@ int scaldpc_qary_configure(scaldpc_qary *h, const char *key, const char *value)
         h->kn_unroll = atoi(value) != 0;
     else if (!strcmp(key, "tree"))
         h->kn_tree = atoi(value) != 0;
+    else if (!strcmp(key, "timing"))
+        h->kn_timing = atoi(value) != 0;
     else
         return fail(SCALDPC_EINVAL, "unknown knob %s", key);
+    return 0;
+}
+
+int scaldpc_qary_last_timing(scaldpc_qary *h, float *ms, int32_t *info)
+{
+    if (!h || !ms || !info) return fail(SCALDPC_EINVAL, "NULL argument");
+    std::lock_guard<std::mutex> lk(h->mu);
+    if (h->stat_kernel < -1 || h->stat_iters == 0) return fail(SCALDPC_EINVAL, "no timed call yet: configure(\"timing\", \"1\") first");
+    ms[0] = h->stat_ms_check;
+    ms[1] = h->stat_ms_var;
+    ms[2] = h->stat_ms_call;
+    info[0] = h->stat_iters;
+    info[1] = h->stat_kernel;
+    info[2] = h->stat_batch;
+    info[3] = h->maxdc;
     return 0;
 }
 
@@ -1125,6 +1177,7 @@ void scaldpc_qary_destroy(scaldpc_qary *h)
     dev_free(h->d_row_ptr); dev_free(h->d_col_ptr); dev_free(h->d_csc_edge); dev_free(h->d_edge_var);
     dev_free(h->d_edge_h); dev_free(h->d_var_q); dev_free(h->d_var_off); dev_free(h->d_msg); dev_free(h->d_llr);
     dev_free(h->d_pmf); dev_free(h->d_pmf2); dev_free(h->d_hard); dev_free(h->d_out); dev_free(h->d_err);
+    for (auto &e : h->tev) (void)hipEventDestroy(e);
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
     delete h;
 }

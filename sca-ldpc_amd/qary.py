@@ -48,9 +48,22 @@ class _QaryBase:
         return np.ascontiguousarray(H)
 
     def configure(self, **knobs):
-        """wave = -1 (auto) / 0 / 1, unroll = 0 / 1 (include/scaldpc.h, scaldpc_qary_configure)."""
+        """wave = -1 (auto) / 0 / 1, unroll = 0 / 1, tree = 0 / 1, timing = 0 / 1 (include/scaldpc.h, scaldpc_qary_configure)."""
         for k, v in knobs.items():
             _lib.check(self._lib.scaldpc_qary_configure(self._h, k.encode(), str(v).encode()))
+
+    CHECK_KERNELS = ("k_q_check_unrolled<3,7>", "k_q_check_unrolled<5,5>", "k_q_special_check_tree<5,6>",
+                     "k_q_special_check_wave", "k_q_check_wave", "k_q_special_check", "k_q_check")
+
+    def last_timing(self):
+        """HIP-event times of the last call's launches (after `configure(timing=1)`; bench.py's measurement aid):
+        dict(ms_check, ms_var, ms_loop, iterations, check_kernel, batch, max_check_degree)."""
+        ms = (C.c_float * 3)()
+        info = (C.c_int32 * 4)()
+        _lib.check(self._lib.scaldpc_qary_last_timing(self._h, ms, info))
+        return {"ms_check": ms[0], "ms_var": ms[1], "ms_loop": ms[2], "iterations": info[0],
+                "check_kernel": self.CHECK_KERNELS[info[1]] if info[1] >= 0 else None, "batch": info[2],
+                "max_check_degree": info[3]}
 
     def close(self):
         if getattr(self, "_h", None):

@@ -36,3 +36,10 @@ def gather_results(local, total, rank, world, device=None):
     outs = [torch.empty_like(t) for _ in range(world)]
     dist.all_gather(outs, t)
     return np.concatenate([o.cpu().numpy()[: sizes[r]] for r, o in enumerate(outs)])
+
+
+def success_checksum(success):
+    """One number that pins WHICH trials failed, not just how many: the sum of the global indices of the first 1000
+    failed trials.  Trial inputs depend on (seed, global index) only, so a sweep's checksum must not change with the
+    number of ranks (bench.py prints it; `--workload hqc128_mc --trials 1000000 --gpus N` is BASELINE config 5)."""
+    return int(np.flatnonzero(np.asarray(success) == 0)[:1000].sum())

@@ -78,6 +78,31 @@ def test_two_rank_gloo_matches_single_process():
     assert 0 < single.sum() < total  # both outcomes present
 
 
+@pytest.mark.parametrize("world", [2, 3])
+def test_success_checksum_is_independent_of_the_world_size(world):
+    """BASELINE config 5's line carries `success_checksum` (which trials failed): identical for 1, 2 and 3 ranks,
+    ragged splits included (41 = 21 + 20 = 14 + 14 + 13)."""
+    import torch.multiprocessing as mp
+
+    total = 41
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, total, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    full = q.get(timeout=240)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    single = _decode_range(0, total)
+    assert shard.success_checksum(full) == shard.success_checksum(single) and shard.success_checksum(single) > 0
+    assert np.array_equal(full, single)
+
+
 def _run_bench(*argv, **env):
     import subprocess
     import sys
