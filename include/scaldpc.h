@@ -93,6 +93,11 @@ int scaldpc_trim(void);
  * pinned-host bytes, parked (idle) blocks, parked bytes }.  A create / decode / destroy cycle must leave
  * out[0..3] where it found them -- the reference builds a decoder per decode (simulate/hqc.py:694-708). */
 int scaldpc_debug_live_blocks(int64_t *out);
+/* Fault injection (tests): the `countdown`-th allocation the library makes from now on (device or pinned host,
+ * any handle, any thread) fails with SCALDPC_ENOMEM; 0 disarms.  Every entry point must then return an error
+ * code, leave the handle either intact or refusing further calls (never decoding on half-updated state), and
+ * scaldpc_*_destroy must still release everything (scaldpc_debug_live_blocks back at its starting value). */
+int scaldpc_debug_fail_alloc(int32_t countdown);
 
 /* ------------------------------------------------------------------ binary BP */
 typedef struct scaldpc_bp scaldpc_bp;

@@ -45,6 +45,8 @@ def _declare(lib):
     lib.scaldpc_trim.restype = C.c_int
     lib.scaldpc_debug_live_blocks.argtypes = [p(C.c_int64)]
     lib.scaldpc_debug_live_blocks.restype = C.c_int
+    lib.scaldpc_debug_fail_alloc.argtypes = [C.c_int32]
+    lib.scaldpc_debug_fail_alloc.restype = C.c_int
     lib.scaldpc_bp_create.argtypes = [C.c_int32, C.c_int32, C.c_int64, vp, vp, p(vp)]
     lib.scaldpc_bp_set_channel_probs.argtypes = [vp, vp]
     lib.scaldpc_bp_decode_batch.argtypes = [

@@ -141,6 +141,10 @@ class BpDecoder:
             raise ValueError("append_rows expects CSR arrays of the new rows (row_ptr[0] = 0, len(col_idx) = row_ptr[-1])")
         if tail.shape != (new_n - self.n,):
             raise ValueError(f"channel_probs_tail must hold the priors of the {new_n - self.n} new columns")
+        # validated BEFORE the graph grows: a bad prior must not leave a grown decoder with unset priors behind
+        if tail.size and not bool(((tail >= 0.0) & (tail <= 1.0)).all()):
+            bad = int(np.flatnonzero(~((tail >= 0.0) & (tail <= 1.0)))[0])
+            raise ValueError(f"channel_probs[{self.n + bad}] = {tail[bad]} is not a probability")
         old_n = self.n
         _lib.check(self._lib.scaldpc_bp_append_rows(self._h, rp.size - 1, _lib.ptr(rp), _lib.ptr(ci), new_n))
         self.m += rp.size - 1

@@ -175,6 +175,9 @@ struct scaldpc_bp {
     // (or destroy) releases a buffer, so this handle's blocks go back through hipFree (which
     // waits for the device) instead of being parked for immediate reuse.
     bool async_used = false;
+    // Set when scaldpc_bp_append_rows failed part-way (an allocation, a copy): host mirrors and device arrays may
+    // disagree, so every later call on the handle returns an error instead of decoding on it; destroy still frees all.
+    bool broken = false;
     int last_group = 0;  // tiles of the last decoded group (for scaldpc_bp_time_kernels)
     std::mutex mu;
 };
@@ -1237,7 +1240,13 @@ int grow_keep(T **p, size_t *cap, size_t used, size_t need)
     const size_t ncap = need + need / 2 + 256;
     T *q = nullptr;
     SC_TRY(dev_alloc(&q, ncap));
-    if (used) SC_HIP(hipMemcpy(q, *p, used * sizeof(T), hipMemcpyDeviceToDevice));
+    if (used) {
+        const hipError_t e = hipMemcpy(q, *p, used * sizeof(T), hipMemcpyDeviceToDevice);
+        if (e != hipSuccess) {
+            dev_free(q);
+            return fail(SCALDPC_EHIP, "copy into the grown buffer failed: %s", hipGetErrorString(e));
+        }
+    }
     dev_free(*p);
     *p = q;
     *cap = ncap;
@@ -1310,6 +1319,7 @@ int scaldpc_bp_set_channel_probs(scaldpc_bp *h, const double *probs)
 {
     if (!h || !probs) return fail(SCALDPC_EINVAL, "NULL argument");
     std::lock_guard<std::mutex> lk(h->mu);
+    if (h->broken) return fail(SCALDPC_EHIP, "this decoder is unusable: an earlier scaldpc_bp_append_rows failed part-way; destroy it and build a new one");
     DeviceGuard dg(h->device);
     std::vector<float> llr(h->n);
     float last_p = 0.0f, last_llr = 0.0f;
@@ -1338,6 +1348,7 @@ int scaldpc_bp_set_channel_probs_tail(scaldpc_bp *h, int32_t first, int32_t coun
 {
     if (!h || (count > 0 && !probs)) return fail(SCALDPC_EINVAL, "NULL argument");
     std::lock_guard<std::mutex> lk(h->mu);
+    if (h->broken) return fail(SCALDPC_EHIP, "this decoder is unusable: an earlier scaldpc_bp_append_rows failed part-way; destroy it and build a new one");
     DeviceGuard dg(h->device);
     if (first < 0 || count < 0 || (long)first + count > h->n)
         return fail(SCALDPC_EINVAL, "columns [%d, %d) are outside the graph (n = %d)", first, first + count, h->n);
@@ -1369,6 +1380,7 @@ int scaldpc_bp_append_rows(scaldpc_bp *h, int32_t nrows, const int32_t *row_ptr,
 {
     if (!h || nrows < 0 || (nrows > 0 && !row_ptr)) return fail(SCALDPC_EINVAL, "bad arguments");
     std::lock_guard<std::mutex> lk(h->mu);
+    if (h->broken) return fail(SCALDPC_EHIP, "this decoder is unusable: an earlier scaldpc_bp_append_rows failed part-way; destroy it and build a new one");
     DeviceGuard dg(h->device);
     CacheBypass guard(h->async_used);
     if (new_n < h->n) return fail(SCALDPC_EINVAL, "new_n = %d is smaller than the current block length %d", new_n, h->n);
@@ -1387,15 +1399,23 @@ int scaldpc_bp_append_rows(scaldpc_bp *h, int32_t nrows, const int32_t *row_ptr,
     if (nrows == 0 && new_n == h->n) return 0;
     if (h->async_used) SC_HIP(hipDeviceSynchronize());  // the tables below may still be read by work in flight
     TMARK("app:start");
+    // From here on the handle is being rebuilt in place.  A failure below (an allocation, a copy) leaves host mirrors
+    // and device arrays in disagreement: the handle is then marked broken and refuses every later call.
+    struct Unfinished {
+        scaldpc_bp *h;
+        bool done = false;
+        ~Unfinished() { if (!done) h->broken = true; }
+    } unfinished{h};
     SC_TRY(make_incremental(h));
     hipStream_t s = h->own_stream;
     const int m0 = h->m, n0 = h->n;
     const long E0 = h->E;
+    // (each view is re-pointed right after its own buffer moved: a later failure must not leave it dangling)
     SC_TRY(grow_keep(&h->d_csr_rp, &h->cap_rows, (size_t)m0 + 1, (size_t)m0 + 1 + nrows));
-    SC_TRY(grow_keep(&h->d_csr_ci, &h->cap_edges, (size_t)E0, (size_t)E0 + add));
-    SC_TRY(grow_keep(&h->d_prior_buf, &h->cap_cols, (size_t)n0, (size_t)new_n));
     h->d_row_ptr = h->d_csr_rp;
+    SC_TRY(grow_keep(&h->d_csr_ci, &h->cap_edges, (size_t)E0, (size_t)E0 + add));
     h->d_col_idx = h->d_csr_ci;
+    SC_TRY(grow_keep(&h->d_prior_buf, &h->cap_cols, (size_t)n0, (size_t)new_n));
     h->d_prior = h->d_prior_buf;
 
     // ---- host mirror: CSR, column degrees ------------------------------------------------------
@@ -1532,6 +1552,7 @@ int scaldpc_bp_append_rows(scaldpc_bp *h, int32_t nrows, const int32_t *row_ptr,
     }
     h->last_group = 0;
     TMARK("app:tail");
+    unfinished.done = true;
     return 0;
 }
 
@@ -1574,6 +1595,7 @@ int scaldpc_bp_decode_batch(scaldpc_bp *h, const uint8_t *in, int32_t input_kind
         return fail(SCALDPC_EINVAL, "unknown bp method %d", method);
     if (!(alpha >= 0.0f)) return fail(SCALDPC_EINVAL, "ms_scaling_factor must be >= 0");
     std::lock_guard<std::mutex> lk(h->mu);
+    if (h->broken) return fail(SCALDPC_EHIP, "this decoder is unusable: an earlier scaldpc_bp_append_rows failed part-way; destroy it and build a new one");
     DeviceGuard dg(h->device);
     if (!h->have_prior || h->prior_n < h->n)
         return fail(SCALDPC_EINVAL, "channel probabilities not set (columns [%d, %d))", h->have_prior ? h->prior_n : 0, h->n);
@@ -1835,6 +1857,7 @@ int scaldpc_mc_fer_run(scaldpc_bp *h, int64_t first_trial, int32_t batch, uint64
 {
     SC_TRY(mc_common_args(h, batch, method, alpha, out_success));
     std::lock_guard<std::mutex> lk(h->mu);
+    if (h->broken) return fail(SCALDPC_EHIP, "this decoder is unusable: an earlier scaldpc_bp_append_rows failed part-way; destroy it and build a new one");
     DeviceGuard dg(h->device);
     CacheBypass guard(h->async_used);
     if (!h->have_prior || h->prior_n < h->n)
@@ -1875,6 +1898,7 @@ int scaldpc_mc_hqc_run(scaldpc_bp *h, int32_t omega, double eps, int64_t first_t
 {
     SC_TRY(mc_common_args(h, batch, method, alpha, out_success));
     std::lock_guard<std::mutex> lk(h->mu);
+    if (h->broken) return fail(SCALDPC_EHIP, "this decoder is unusable: an earlier scaldpc_bp_append_rows failed part-way; destroy it and build a new one");
     DeviceGuard dg(h->device);
     CacheBypass guard(h->async_used);
     if (!h->have_prior || h->prior_n < h->n)
@@ -1970,6 +1994,7 @@ int scaldpc_bp_time_kernels(scaldpc_bp *h, int32_t iters, int32_t method, float 
 {
     if (!h || !ms || !launches || iters <= 0) return fail(SCALDPC_EINVAL, "bad argument");
     std::lock_guard<std::mutex> lk(h->mu);
+    if (h->broken) return fail(SCALDPC_EHIP, "this decoder is unusable: an earlier scaldpc_bp_append_rows failed part-way; destroy it and build a new one");
     DeviceGuard dg(h->device);
     if (h->last_group <= 0) return fail(SCALDPC_EINVAL, "no previous decode to time");
     hipStream_t s = stream ? (hipStream_t)stream : h->own_stream;

@@ -3,6 +3,7 @@
 // recycled streams, and the handful of C-ABI entry points that belong to no handle.
 #include "scaldpc_common.h"
 
+#include <atomic>
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
@@ -77,9 +78,14 @@ int poison(void *p, size_t bytes, bool pinned_host)
 CacheBypass::CacheBypass(bool on) : prev(tl_bypass) { tl_bypass = prev || on; }
 CacheBypass::~CacheBypass() { tl_bypass = prev; }
 
+// scaldpc_debug_fail_alloc (tests): the k-th allocation from now fails with SCALDPC_ENOMEM
+std::atomic<int> fail_countdown{0};
+
 int cached_alloc(void **p, size_t bytes, bool pinned_host)
 {
     *p = nullptr;
+    if (fail_countdown.load(std::memory_order_relaxed) > 0 && fail_countdown.fetch_sub(1) == 1)
+        return fail(SCALDPC_ENOMEM, "allocation of %zu bytes failed: injected by scaldpc_debug_fail_alloc", bytes);
     bytes = (bytes + 255) / 256 * 256;
     int dev = -1;
     if (!pinned_host) SC_HIP(hipGetDevice(&dev));
@@ -215,6 +221,12 @@ int scaldpc_debug_live_blocks(int64_t *out)
     }
     out[4] = (int64_t)bc.idle.size();
     out[5] = (int64_t)bc.idle_bytes;
+    return 0;
+}
+
+int scaldpc_debug_fail_alloc(int32_t countdown)
+{
+    fail_countdown.store(countdown > 0 ? countdown : 0);
     return 0;
 }
 

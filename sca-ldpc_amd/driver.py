@@ -298,17 +298,39 @@ class HqcCheckAccumulator:
             self._bpd_omega = omega
         elif R > self._bpd_R:
             k = R - self._bpd_R
-            with np.errstate(divide="ignore"):
-                self._bpd.append_rows(np.arange(k + 1, dtype=np.int32) * (W + 1), self._cols[self._bpd_R : R].reshape(-1),
-                                      self.N + R, 1 - self._cert[self._bpd_R : R])
+            try:
+                with np.errstate(divide="ignore"):
+                    self._bpd.append_rows(np.arange(k + 1, dtype=np.int32) * (W + 1), self._cols[self._bpd_R : R].reshape(-1),
+                                          self.N + R, 1 - self._cert[self._bpd_R : R])
+            except Exception:
+                # a failed append (a certainty outside [0, 1], no memory) must not wedge the accumulator: drop the live
+                # decoder, so that the next decode builds a fresh one -- the reference's behaviour on every decode
+                self.close()
+                raise
         self._bpd_R = R
         return self._bpd
 
     def close(self):
+        """Release the live decoder (device memory, stream).  The accumulator stays usable: the next decode builds a
+        new decoder from all the checks.  Call it -- or use the accumulator as a context manager -- when the attack is
+        over; rows are APPEND-ONLY (`add_check`), which is what lets the live decoder be extended instead of rebuilt."""
         if self._bpd is not None and hasattr(self._bpd, "close"):
             self._bpd.close()
         self._bpd = None
         self._bpd_R = 0
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+        return False
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
     def decode(self, y_sparse):
         """hqc.py:661-759 on the accumulated checks; appends the stats row (hqc.py:750-758)."""
@@ -332,6 +354,7 @@ class HqcCheckAccumulator:
             if self.decode_every and R % self.decode_every == 0 and self._previous_decoding != R:
                 self._previous_decoding = R
                 if self.decode(y_sparse):
+                    self.close()  # the attack is over (hqc.py:976-980 returns here): give the GPU decoder back
                     return True
         return False
 

@@ -138,3 +138,86 @@ def test_one_handle_with_growing_and_shrinking_calls_without_the_block_cache():
     env.pop("SCALDPC_PATH", None)
     r = subprocess.run([sys.executable, "-c", CHILD, ROOT], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "child ok" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+def test_failed_append_leaves_a_refusing_handle_and_no_leak():
+    """scaldpc_bp_append_rows with the k-th allocation failing (scaldpc_debug_fail_alloc), k = 1, 2, ...: the call
+    returns an error code (MemoryError here), the handle then REFUSES further calls -- host mirrors and device arrays
+    may disagree, decoding on them would be undefined -- and destroy still releases every block.  Once k is past the
+    allocations an append makes, the append succeeds and the decoder gives the fresh decoder's answers.  Both kinds
+    of append are injected into: the first one of a handle (its arrays move to growable allocations) and a later one
+    (row-parallel tables updated in place)."""
+    L = lib.load()
+    H, Hin, probs, msg, y = hqc_instance(997, 9, 300, 6, 0.03, 3, seed=41)
+    N = 997
+
+    def part(r):  # the first r rows of [Hin | I]: graph, priors, inputs
+        g = S.TannerGraph.from_csr(r, N + r, H.row_ptr[: r + 1].copy(), H.col_idx[: H.row_ptr[r]].copy())
+        return g, np.concatenate([probs[:N], probs[N:N + r]]), np.concatenate([msg[:, :N], msg[:, N:N + r]], axis=1)
+
+    def rows(r0, r1):  # CSR of rows [r0, r1), the block length afterwards, the priors of their identity columns
+        rp = H.row_ptr[r0:r1 + 1].astype(np.int64)
+        return (rp - rp[0]).astype(np.int32), H.col_idx[rp[0]:rp[-1]], N + r1, probs[N + r0:N + r1]
+
+    fresh = bp.bp_decoder(H, max_iter=30, bp_method="min_sum", channel_probs=probs)
+    fresh.configure(path="edge")
+    want = fresh.decode_batch(msg, want_llr=True)
+    fresh.close()
+    base = live()
+    for first_append in (True, False):
+        failed = succeeded = 0
+        for k in range(1, 40):
+            g0, p0, x0 = part(100)
+            dec = bp.bp_decoder(g0, max_iter=30, bp_method="min_sum", channel_probs=p0)
+            dec.configure(path="edge")
+            dec.decode_batch(x0)
+            r0 = 100
+            if not first_append:
+                dec.append_rows(*rows(100, 150))
+                dec.decode_batch(part(150)[2])  # the row-parallel tables of the growable handle exist now
+                r0 = 150
+            L.scaldpc_debug_fail_alloc(k)
+            try:
+                dec.append_rows(*rows(r0, 300))
+                L.scaldpc_debug_fail_alloc(0)
+                got = dec.decode_batch(msg, want_llr=True)
+                for key in ("bits", "llr", "iters", "converged"):
+                    assert np.array_equal(got[key], want[key]), (k, key)
+                succeeded += 1
+            except MemoryError:
+                L.scaldpc_debug_fail_alloc(0)
+                failed += 1
+                with pytest.raises(Exception, match="unusable"):
+                    dec.decode_batch(msg)
+                with pytest.raises(Exception, match="unusable"):
+                    dec.append_rows(*rows(r0, 300))
+            dec.close()
+            assert live() == base, f"k = {k}: {live()} != {base}"
+            if succeeded >= 2:
+                break
+        assert failed >= 1 and succeeded >= 2, (first_append, failed, succeeded)
+
+
+def test_accumulator_survives_a_bad_certainty():
+    """driver.HqcCheckAccumulator keeps ONE decoder alive and appends rows to it; a certainty outside [0, 1] fails the
+    append BEFORE the graph grows (bp.append_rows validates first) and the accumulator drops its live decoder instead
+    of re-entering the failed append on every later decode."""
+    driver = importlib.import_module("sca-ldpc_amd.driver")
+    rng = np.random.RandomState(5)
+    N, W, omega = 499, 7, 5
+    first = np.sort(rng.choice(N, W, replace=False))
+    ysp = list(rng.choice(N, omega, replace=False))
+    base = live()
+    with driver.HqcCheckAccumulator(N, first, omega, max_iter=30) as acc:
+        for b in range(40):
+            acc.add_check(int(rng.randint(N)), 0, 0.9)
+        acc.decode(ysp)
+        assert acc._bpd is not None and live() != base
+        acc.add_check(3, 1, 1.5)  # certainty 1.5 -> prior -0.5
+        with pytest.raises(ValueError, match="not a probability"):
+            acc.decode(ysp)
+        assert acc._bpd is None and live() == base  # dropped, nothing left behind
+        acc._cert[acc._R - 1] = 0.8  # the caller repairs its data: the next decode builds a fresh decoder
+        acc.decode(ysp)
+        assert acc._bpd is not None
+    assert live() == base  # context manager closed it
