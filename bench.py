@@ -634,6 +634,19 @@ def qary_bench(args, S, rank, world, dist, backend, local, iters):
                 "share_of_loop_time": kt["ms_check"] / max(kt["ms_loop"], 1e-9),
             },
         }
+        if args.workload.startswith("criterion"):
+            # point-mass channel outputs: almost every message entry is +inf and the reference enumerates finite
+            # supports only (decoder.rs:281-401) -- a handful of assignments per check, nothing like Q^(k-1).  The call
+            # is LAUNCH-bound: 2 * iterations + 4 launches and two copies around microseconds of arithmetic.
+            launches = 2 * kt["iterations"] + 4
+            line["roofline"] = {
+                "bound": "launch", "kernel": kt["check_kernel"], "unit": "launches/s", "achieved": launches * args.steps * world / dt,
+                "peak": None, "frac": None, "traffic": None, "launches_per_call": launches,
+                "device_loop_ms": kt["ms_loop"], "call_ms": dt / args.steps * 1e3,
+                "what": "batch-1 latency of the reference's criterion case; no VALU / HBM fraction is claimed: the work is a few "
+                        "finite-support assignments per check, the time is launch and copy latency (see cpu_baseline: one host "
+                        "core finishes the same call sooner)",
+            }
         if per_rank_ms:
             line["per_rank_ms_per_step"] = per_rank_ms
         if args.parity_rows > 0:
