@@ -1,0 +1,387 @@
+// Microbenchmark (evidence for DESIGN.md section 7, not product code): would ONE persistent launch pay for the
+// attack loop's single decode()?  The reference's production call is one codeword on the HQC-128 graph
+// (n = 21 669, E = 204 000), up to 100 iterations (hqc.py:696,708); the row-parallel path runs it as two launches
+// per iteration (k_el_check with the fused convergence test, k_el_var) at ~19 us per iteration.
+//
+//   (a) two launches per iteration, the product's schedule: check rows (wave = row, lane = edge, tanh rule in the
+//       reference's order, fused H e == s test of the previous decisions), variable columns (lane = edge of a packed
+//       column segment, exclusive prefix / suffix sums by shuffles)
+//   (b) the same two phases inside ONE launch, whole chip: 256 workgroups x 1024 threads, a grid barrier after each
+//       phase (XCD-hierarchical: per-group counter -> top counter -> per-group generation word), messages and hard
+//       decisions moved with agent-scope (sc1) loads / stores so that no fence is needed
+//   (c) the same on ONE XCD: 8 x 32 workgroups launched, only those with blockIdx % 8 == 0 work (round-robin
+//       placement puts them on one XCD: speed only, the barrier does not depend on it); one counter
+//   (d) as (c) with two workgroups per CU (8 x 64 launched)
+// All variants run ITERS iterations without converging (random syndrome) and are checked against (a)'s messages.
+// Every spin is bounded: a barrier that does not complete sets an error flag and lets the grid drain.
+// build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -o persistent_bp persistent_bp.hip
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cfloat>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <numeric>
+#include <random>
+#include <vector>
+#define CK(x) do { hipError_t e__ = (x); if (e__ != hipSuccess) { printf("%s: %s (line %d)\n", #x, hipGetErrorString(e__), __LINE__); return 1; } } while (0)
+
+typedef unsigned long long u64;
+constexpr int N = 17669, R = 4000, W = 50, NN = N + R, ITERS = 100;
+constexpr long E = (long)R * (W + 1);
+
+__device__ __forceinline__ int rfl(int x) { return __builtin_amdgcn_readfirstlane(x); }
+__device__ __forceinline__ float tanh_compl(float a) { return 2.0f * __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(a * 1.44269504088896340736f) + 1.0f); }
+__device__ __forceinline__ float llr_from_compl(float U) { return __builtin_amdgcn_logf(fmaf(2.0f, __builtin_amdgcn_rcpf(U), -1.0f)) * 0.69314718055994530942f; }
+__device__ __forceinline__ float compl_step(float U, float u) { return fmaf(u, 1.0f - U, U); }
+__device__ __forceinline__ float readlane_f(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
+
+// COHERENT: loads / stores another workgroup's data crosses without a kernel boundary -> agent scope (sc1)
+template <bool COHERENT> __device__ __forceinline__ float ld(const float *p)
+{
+    if (COHERENT) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return *p;
+}
+template <bool COHERENT> __device__ __forceinline__ void st(float *p, float v)
+{
+    if (COHERENT) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else *p = v;
+}
+template <bool COHERENT> __device__ __forceinline__ unsigned ldu(const unsigned *p)
+{
+    if (COHERENT) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return *p;
+}
+
+// one row, one wave: lane = edge.  `hard` = one word per variable (bit 0 = the codeword's decision).
+template <bool COHERENT, bool FIRST>
+__device__ __forceinline__ void check_row(int r, int lane, const int *__restrict__ row_ptr, const int *__restrict__ col_idx,
+                                          const float *__restrict__ prior, float *emsg, const unsigned *__restrict__ synd,
+                                          const unsigned *hard, int *unsat_prev)
+{
+    const int e0 = rfl(row_ptr[r]);
+    const int deg = rfl(row_ptr[r + 1]) - e0;
+    const bool act = lane < deg;
+    const unsigned sbit = synd[r] & 1u;
+    const int col = act ? col_idx[e0 + lane] : 0;
+    if (unsat_prev) {
+        const unsigned hb = act ? ldu<COHERENT>(hard + col) & 1u : 0u;
+        if ((((unsigned)__popcll(__ballot(hb != 0u)) & 1u) ^ sbit) && lane == 0) atomicOr(unsat_prev, 1);
+    }
+    float *p = emsg + e0 + lane;
+    float x = 0.0f;
+    if (act) x = FIRST ? prior[col] : ld<COHERENT>(p);
+    const unsigned xb = act ? __float_as_uint(x) : 0u;
+    const float u = act ? tanh_compl(fabsf(x)) : 0.0f;
+    const unsigned par = sbit ^ ((unsigned)__popcll(__ballot((xb >> 31) != 0u)) & 1u);
+    float pre = 0.0f, suf = 0.0f;
+#pragma unroll 4
+    for (int t = 0; t < deg; t++) {
+        const float nv = compl_step(pre, readlane_f(u, t));
+        pre = (t < lane) ? nv : pre;
+    }
+#pragma unroll 4
+    for (int t = deg - 1; t >= 0; t--) {
+        const float nv = compl_step(suf, readlane_f(u, t));
+        suf = (t > lane) ? nv : suf;
+    }
+    const float Lm = llr_from_compl(compl_step(pre, suf));
+    const unsigned sg = ((par << 31) ^ xb) & 0x80000000u;
+    if (act) st<COHERENT>(p, __uint_as_float(__float_as_uint(Lm) ^ sg));
+}
+
+// one packed wave of column segments: slot = {edge id or -1, start | pos << 6 | deg << 12}; slot_col at segment heads
+template <bool COHERENT>
+__device__ __forceinline__ void var_wave(int w, int lane, const int2 *__restrict__ slots, const int *__restrict__ slot_col,
+                                         const float *__restrict__ prior, float *emsg, unsigned *hard)
+{
+    const int2 sl = slots[(size_t)w * 64 + lane];
+    const int e = sl.x, start = sl.y & 63, pos = (sl.y >> 6) & 63, deg = (sl.y >> 12) & 127;
+    const bool head = e >= 0 && pos == 0;
+    int dmax = deg;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) dmax = max(dmax, __shfl_xor(dmax, off));
+    dmax = rfl(dmax);
+    const float mk = e >= 0 ? ld<COHERENT>(emsg + e) : 0.0f;
+    int v = 0;
+    float pr = 0.0f;
+    if (head) {
+        v = slot_col[(size_t)w * 64 + lane];
+        pr = prior[v];
+    }
+    pr = __shfl(pr, start);
+    float pre = pr, tot = pr, suf = 0.0f;
+    for (int t = 0; t < dmax; t++) {
+        const float val = __shfl(mk, (start + t) & 63);
+        pre = (t < pos) ? pre + val : pre;
+        tot = (t < deg) ? tot + val : tot;
+    }
+    for (int t = dmax - 1; t >= 0; t--) {
+        const float val = __shfl(mk, (start + t) & 63);
+        suf = (t > pos && t < deg) ? suf + val : suf;
+    }
+    if (e >= 0) st<COHERENT>(emsg + e, pre + suf);
+    if (head) {
+        const unsigned hv = tot <= 0.0f ? 1u : 0u;
+        if (COHERENT) __hip_atomic_store(hard + v, hv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else hard[v] = hv;
+    }
+}
+
+// ---- (a) the product's schedule: two launches per iteration ---------------------------------------------------
+template <bool FIRST>
+__global__ __launch_bounds__(256) void k_check(const int *row_ptr, const int *col_idx, const float *prior, float *emsg,
+                                               const unsigned *synd, const unsigned *hard, int *unsat_prev)
+{
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= R) return;
+    check_row<false, FIRST>(rfl(r), threadIdx.x & 63, row_ptr, col_idx, prior, emsg, synd, hard, unsat_prev);
+}
+__global__ __launch_bounds__(256) void k_var(const int2 *slots, const int *slot_col, int nwaves, const float *prior, float *emsg,
+                                             unsigned *hard, const int *unsat_prev, int *done)
+{
+    const int w = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (w >= nwaves) return;
+    if (unsat_prev && *unsat_prev == 0) {  // converged at the previous iteration: outputs stay
+        if (w == 0 && (threadIdx.x & 63) == 0) *done = 1;
+        return;
+    }
+    var_wave<false>(rfl(w), threadIdx.x & 63, slots, slot_col, prior, emsg, hard);
+}
+
+// ---- grid barriers ----------------------------------------------------------------------------------------------
+struct Bar {
+    unsigned *top;   // one counter
+    unsigned *grp;   // 8 group counters, 32 words (128 B) apart
+    unsigned *gen;   // 8 generation words, 32 words apart
+    int *error;
+};
+constexpr int SPIN_LIMIT = 1 << 20;
+
+// one monotonic counter: every workgroup adds once per barrier, then polls until phase * nblocks
+__device__ __forceinline__ void barrier_flat(const Bar &b, unsigned nblocks, unsigned phase)
+{
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __hip_atomic_fetch_add(b.top, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        int spins = 0;
+        while (__hip_atomic_load(b.top, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < phase * nblocks) {
+            __builtin_amdgcn_s_sleep(1);
+            if (++spins > SPIN_LIMIT) { atomicExch(b.error, 1); break; }
+        }
+    }
+    __syncthreads();
+}
+// hierarchical: group g = blockIdx % 8 (an XCD under round-robin placement); the group's last arriver goes to the top
+// counter, waits for all 8 groups, then publishes the group's generation word, which the others poll
+__device__ __forceinline__ void barrier_xcd(const Bar &b, unsigned per_group, unsigned phase)
+{
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned g = blockIdx.x & 7u;
+        const unsigned old = __hip_atomic_fetch_add(b.grp + 32 * g, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        int spins = 0;
+        if (old + 1 == phase * per_group) {  // last of the group
+            __hip_atomic_fetch_add(b.top, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            while (__hip_atomic_load(b.top, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < phase * 8u) {
+                __builtin_amdgcn_s_sleep(1);
+                if (++spins > SPIN_LIMIT) { atomicExch(b.error, 1); break; }
+            }
+            __hip_atomic_store(b.gen + 32 * g, phase, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            while (__hip_atomic_load(b.gen + 32 * g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < phase) {
+                __builtin_amdgcn_s_sleep(1);
+                if (++spins > SPIN_LIMIT) { atomicExch(b.error, 1); break; }
+            }
+        }
+    }
+    __syncthreads();
+}
+
+// ---- (b) (c) (d): one launch, ITERS iterations ----------------------------------------------------------------
+// STRIDE8: only workgroups with blockIdx % 8 == 0 take part (one XCD), flat barrier; else all, hierarchical barrier
+template <bool STRIDE8>
+__global__ __launch_bounds__(1024) void k_persistent(const int *row_ptr, const int *col_idx, const float *prior, float *emsg,
+                                                     const unsigned *synd, unsigned *hard, const int2 *slots,
+                                                     const int *slot_col, int nwaves, int *unsat /* [ITERS + 1] */, Bar bar,
+                                                     int iters, int *iters_run)
+{
+    if (STRIDE8 && (blockIdx.x & 7)) return;
+    const int nb = STRIDE8 ? gridDim.x / 8 : gridDim.x, b = STRIDE8 ? blockIdx.x / 8 : blockIdx.x;
+    const int lane = threadIdx.x & 63, wv = b * 16 + (threadIdx.x >> 6), nw = nb * 16;
+    unsigned phase = 0;
+    int it = 1;
+    for (; it <= iters; it++) {
+        int *up = it > 1 ? unsat + it : nullptr;
+        if (it == 1)
+            for (int r = wv; r < R; r += nw) check_row<true, true>(rfl(r), lane, row_ptr, col_idx, prior, emsg, synd, hard, up);
+        else
+            for (int r = wv; r < R; r += nw) check_row<true, false>(rfl(r), lane, row_ptr, col_idx, prior, emsg, synd, hard, up);
+        ++phase;
+        if (STRIDE8) barrier_flat(bar, nb, phase); else barrier_xcd(bar, nb / 8, phase);
+        // the verdict on iteration it - 1's decisions: everybody reads the same flag after the barrier
+        if (it > 1 && __hip_atomic_load(unsat + it, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) break;
+        if (*bar.error) break;
+        for (int w = wv; w < nwaves; w += nw) var_wave<true>(rfl(w), lane, slots, slot_col, prior, emsg, hard);
+        ++phase;
+        if (STRIDE8) barrier_flat(bar, nb, phase); else barrier_xcd(bar, nb / 8, phase);
+    }
+    if (b == 0 && threadIdx.x == 0) *iters_run = it - 1;
+}
+
+int main()
+{
+    std::mt19937 rng(12345);
+    // ---- graph: R rows of W distinct random columns < N, then the identity column; CSR ascending
+    std::vector<int> row_ptr(R + 1), col_idx(E);
+    std::vector<std::vector<int>> col_edges(NN);
+    for (int r = 0; r < R; r++) {
+        row_ptr[r] = r * (W + 1);
+        std::vector<int> cs;
+        while ((int)cs.size() < W) {
+            int c = (int)(rng() % N);
+            if (std::find(cs.begin(), cs.end(), c) == cs.end()) cs.push_back(c);
+        }
+        std::sort(cs.begin(), cs.end());
+        cs.push_back(N + r);
+        for (int k = 0; k <= W; k++) {
+            col_idx[(size_t)r * (W + 1) + k] = cs[k];
+            col_edges[cs[k]].push_back(r * (W + 1) + k);
+        }
+    }
+    row_ptr[R] = (int)E;
+    // ---- packed column segments, degree-sorted (the product's fresh-decoder packing)
+    std::vector<int> order(NN);
+    std::iota(order.begin(), order.end(), 0);
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return col_edges[a].size() < col_edges[b].size(); });
+    std::vector<int2> slots;
+    std::vector<int> slot_col;
+    int used = 64;
+    for (int c : order) {
+        const int d = (int)col_edges[c].size(), cap = std::max(d, 1);
+        if (cap > 64) { printf("column too wide\n"); return 1; }
+        if (used + cap > 64) {
+            slots.resize(slots.size() + 64, int2{-1, 0});
+            slot_col.resize(slot_col.size() + 64, 0);
+            used = 0;
+        }
+        const size_t base = slots.size() - 64 + used;
+        for (int k = 0; k < cap; k++) slots[base + k] = int2{k < d ? col_edges[c][k] : -1, used | (k << 6) | (d << 12)};
+        if (d == 0) slots[base].x = -1;
+        slot_col[base] = c;
+        used += cap;
+    }
+    const int nwaves = (int)(slots.size() / 64);
+    std::vector<float> prior(NN);
+    const float p0 = logf((1.0f - 66.0f / N) / (66.0f / N)), p1 = logf(0.95f / 0.05f);
+    for (int v = 0; v < NN; v++) prior[v] = v < N ? p0 : p1;
+    std::vector<unsigned> synd(R);
+    for (auto &s : synd) s = rng() & 1u;  // a random syndrome: never converges
+    printf("graph: R=%d n=%d E=%ld, %d packed column waves\n", R, NN, E, nwaves);
+
+    int *d_rp, *d_ci, *d_slot_col, *d_unsat, *d_done, *d_iters, *d_err;
+    int2 *d_slots;
+    float *d_prior, *d_msg_a, *d_msg_b;
+    unsigned *d_synd, *d_hard, *d_bar;
+    CK(hipMalloc(&d_rp, sizeof(int) * (R + 1)));
+    CK(hipMalloc(&d_ci, sizeof(int) * E));
+    CK(hipMalloc(&d_slots, sizeof(int2) * slots.size()));
+    CK(hipMalloc(&d_slot_col, sizeof(int) * slot_col.size()));
+    CK(hipMalloc(&d_prior, sizeof(float) * NN));
+    CK(hipMalloc(&d_msg_a, sizeof(float) * E));
+    CK(hipMalloc(&d_msg_b, sizeof(float) * E));
+    CK(hipMalloc(&d_synd, sizeof(unsigned) * R));
+    CK(hipMalloc(&d_hard, sizeof(unsigned) * NN));
+    CK(hipMalloc(&d_unsat, sizeof(int) * (ITERS + 2)));
+    CK(hipMalloc(&d_done, sizeof(int)));
+    CK(hipMalloc(&d_iters, sizeof(int)));
+    CK(hipMalloc(&d_err, sizeof(int)));
+    CK(hipMalloc(&d_bar, sizeof(unsigned) * 32 * 17));
+    CK(hipMemcpy(d_rp, row_ptr.data(), sizeof(int) * (R + 1), hipMemcpyHostToDevice));
+    CK(hipMemcpy(d_ci, col_idx.data(), sizeof(int) * E, hipMemcpyHostToDevice));
+    CK(hipMemcpy(d_slots, slots.data(), sizeof(int2) * slots.size(), hipMemcpyHostToDevice));
+    CK(hipMemcpy(d_slot_col, slot_col.data(), sizeof(int) * slot_col.size(), hipMemcpyHostToDevice));
+    CK(hipMemcpy(d_prior, prior.data(), sizeof(float) * NN, hipMemcpyHostToDevice));
+    CK(hipMemcpy(d_synd, synd.data(), sizeof(unsigned) * R, hipMemcpyHostToDevice));
+    hipStream_t s;
+    CK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0));
+    CK(hipEventCreate(&e1));
+
+    // ---- (a) two launches per iteration
+    auto run_a = [&](float *msg) -> int {
+        CK(hipMemsetAsync(d_hard, 0, sizeof(unsigned) * NN, s));
+        CK(hipMemsetAsync(d_unsat, 0, sizeof(int) * (ITERS + 2), s));
+        CK(hipMemsetAsync(d_done, 0, sizeof(int), s));
+        for (int it = 1; it <= ITERS; it++) {
+            int *up = it > 1 ? d_unsat + it : nullptr;
+            if (it == 1) hipLaunchKernelGGL(k_check<true>, dim3((R + 3) / 4), dim3(256), 0, s, d_rp, d_ci, d_prior, msg, d_synd, d_hard, up);
+            else hipLaunchKernelGGL(k_check<false>, dim3((R + 3) / 4), dim3(256), 0, s, d_rp, d_ci, d_prior, msg, d_synd, d_hard, up);
+            hipLaunchKernelGGL(k_var, dim3((nwaves + 3) / 4), dim3(256), 0, s, d_slots, d_slot_col, nwaves, d_prior, msg, d_hard, up, d_done);
+        }
+        CK(hipGetLastError());
+        return 0;
+    };
+    if (run_a(d_msg_a)) return 1;
+    CK(hipStreamSynchronize(s));
+    float best_a = 1e9f;
+    for (int rep = 0; rep < 5; rep++) {
+        CK(hipEventRecord(e0, s));
+        if (run_a(d_msg_a)) return 1;
+        CK(hipEventRecord(e1, s));
+        CK(hipStreamSynchronize(s));
+        float ms;
+        CK(hipEventElapsedTime(&ms, e0, e1));
+        best_a = std::min(best_a, ms);
+    }
+    std::vector<float> ref(E), got(E);
+    CK(hipMemcpy(ref.data(), d_msg_a, sizeof(float) * E, hipMemcpyDeviceToHost));
+    printf("(a) two launches per iteration            : %8.1f us per %d-iteration decode = %6.2f us per iteration\n", best_a * 1e3, ITERS, best_a * 1e3 / ITERS);
+
+    // ---- (b)-(d) persistent
+    Bar bar{d_bar, d_bar + 32, d_bar + 32 * 9, d_err};
+    struct Var { const char *name; bool stride8; int grid; };
+    const Var vars[] = {{"(b) one launch, whole chip, 256 x 1024   ", false, 256},
+                        {"(b') one launch, whole chip, 512 x 1024  ", false, 512},
+                        {"(c) one launch, one XCD, 32 x 1024       ", true, 8 * 32},
+                        {"(d) one launch, one XCD, 64 x 1024       ", true, 8 * 64}};
+    for (const Var &v : vars) {
+        float best = 1e9f;
+        int its = 0, err = 0;
+        for (int rep = 0; rep < 6 && !err; rep++) {
+            CK(hipMemsetAsync(d_hard, 0, sizeof(unsigned) * NN, s));
+            CK(hipMemsetAsync(d_unsat, 0, sizeof(int) * (ITERS + 2), s));
+            CK(hipMemsetAsync(d_bar, 0, sizeof(unsigned) * 32 * 17, s));
+            CK(hipMemsetAsync(d_err, 0, sizeof(int), s));
+            CK(hipEventRecord(e0, s));
+            if (v.stride8)
+                hipLaunchKernelGGL(k_persistent<true>, dim3(v.grid), dim3(1024), 0, s, d_rp, d_ci, d_prior, d_msg_b, d_synd, d_hard, d_slots,
+                                   d_slot_col, nwaves, d_unsat, bar, ITERS, d_iters);
+            else
+                hipLaunchKernelGGL(k_persistent<false>, dim3(v.grid), dim3(1024), 0, s, d_rp, d_ci, d_prior, d_msg_b, d_synd, d_hard, d_slots,
+                                   d_slot_col, nwaves, d_unsat, bar, ITERS, d_iters);
+            CK(hipGetLastError());
+            CK(hipEventRecord(e1, s));
+            CK(hipStreamSynchronize(s));
+            float ms;
+            CK(hipEventElapsedTime(&ms, e0, e1));
+            CK(hipMemcpy(&err, d_err, sizeof(int), hipMemcpyDeviceToHost));
+            CK(hipMemcpy(&its, d_iters, sizeof(int), hipMemcpyDeviceToHost));
+            if (rep) best = std::min(best, ms);
+        }
+        if (err) {
+            printf("%s: barrier did not complete (grid not co-resident?) -- skipped\n", v.name);
+            continue;
+        }
+        CK(hipMemcpy(got.data(), d_msg_b, sizeof(float) * E, hipMemcpyDeviceToHost));
+        size_t bad = 0;
+        for (long i = 0; i < E; i++) bad += memcmp(&got[i], &ref[i], 4) != 0;
+        printf("%s: %8.1f us per decode = %6.2f us per iteration (%.2fx of (a)); %d iterations run, %zu of %ld messages differ from (a)\n",
+               v.name, best * 1e3, best * 1e3 / ITERS, best_a / best, its, bad, E);
+    }
+    return 0;
+}
