@@ -67,7 +67,9 @@ __device__ __forceinline__ void check_row(int r, int lane, const int *__restrict
     const int col = act ? col_idx[e0 + lane] : 0;
     if (unsat_prev) {
         const unsigned hb = act ? ldu<COHERENT>(hard + col) & 1u : 0u;
-        if ((((unsigned)__popcll(__ballot(hb != 0u)) & 1u) ^ sbit) && lane == 0) atomicOr(unsat_prev, 1);
+        // a flag, set by any unsatisfied row (two launches: the global word itself; one launch: a word in LDS that the
+        // workgroup publishes once per phase -- 2000 write-through stores to one address would serialise at the fabric)
+        if ((((unsigned)__popcll(__ballot(hb != 0u)) & 1u) ^ sbit) && lane == 0) *unsat_prev = 1;
     }
     float *p = emsg + e0 + lane;
     float x = 0.0f;
@@ -214,12 +216,20 @@ __global__ __launch_bounds__(1024) void k_persistent(const int *row_ptr, const i
     const int lane = threadIdx.x & 63, wv = b * 16 + (threadIdx.x >> 6), nw = nb * 16;
     unsigned phase = 0;
     int it = 1;
+    __shared__ int s_bad;
+    if (threadIdx.x == 0) s_bad = 0;
+    __syncthreads();
     for (; it <= iters; it++) {
-        int *up = it > 1 ? unsat + it : nullptr;
+        int *up = it > 1 ? &s_bad : nullptr;
         if (it == 1)
             for (int r = wv; r < R; r += nw) check_row<true, true>(rfl(r), lane, row_ptr, col_idx, prior, emsg, synd, hard, up);
         else
             for (int r = wv; r < R; r += nw) check_row<true, false>(rfl(r), lane, row_ptr, col_idx, prior, emsg, synd, hard, up);
+        __syncthreads();
+        if (threadIdx.x == 0 && s_bad) {  // one write-through store per workgroup and phase
+            __hip_atomic_store(unsat + it, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s_bad = 0;
+        }
         ++phase;
         if (STRIDE8) barrier_flat(bar, nb, phase); else barrier_xcd(bar, nb / 8, phase);
         // the verdict on iteration it - 1's decisions: everybody reads the same flag after the barrier
