@@ -570,8 +570,10 @@ def qary_reference_ops(g, cls, special):
 
 def qary_bench(args, S, rank, world, dist, backend, local, iters):
     """BASELINE config 4 and its q-ary siblings through the simulate_rs-shaped classes: `--steps` calls of
-    min_sum_batch on `--batch` codewords per rank, host pmf arrays in and symbols out as the PyO3 class takes
-    them (PCIe included; the probability -> LLR conversion runs on the device, k_q_into_llr).
+    min_sum_batch on `--batch` codewords per rank, channel outputs resident in HBM when the timed region starts and
+    symbols left there (the probability -> LLR conversion runs on the device, k_q_into_llr, inside the call); the
+    same call with host arrays in and out -- what the PyO3 class takes, PCIe included -- is timed beside it
+    (`host_buffers`) and must give the same symbols.
     value = directed symbol-edge message updates / s (2 * E * batch * iterations per call).
     roofline: ALU-bound, no HBM claim: reference-ops / s of the check kernel from its HIP-event
     time against the fp32 VALU peak.  cpu_baseline: the C oracle (decoder.rs restated) on the same inputs."""
@@ -584,22 +586,39 @@ def qary_bench(args, S, rank, world, dist, backend, local, iters):
     name, g, inputs, oracle_call, what = qary_case(args.workload, S, batch, rank)
     cls = qary.decoder_class(name)
     dec = cls(g.to_dense(np.int8), iters)
+    dev = torch.device("cuda", local)
+    d_in = [torch.from_numpy(x).to(dev) for x in inputs]  # resident in HBM before the timed region (the contract's `value`)
+    d_out = torch.empty((batch, g.n), dtype=torch.int8, device=dev)
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def step():
+        dec.min_sum_batch_device(*[t.data_ptr() for t in d_in], batch, d_out.data_ptr(), stream=stream)
+
     with np.errstate(divide="ignore"):
         for _ in range(max(1, args.warmup)):
-            out = dec.min_sum_batch(*inputs)
+            step()
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
         t0 = time.perf_counter()
         for _ in range(args.steps):
-            out = dec.min_sum_batch(*inputs)
+            step()
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
         dt = time.perf_counter() - t0
+        out = d_out.cpu().numpy()
+        # the same call as the PyO3 class takes it: host arrays in, symbols out (PCIe both ways) -- reported, never `value`
+        for _ in range(2):
+            out_host = dec.min_sum_batch(*inputs)
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            out_host = dec.min_sum_batch(*inputs)
+        dt_host = (time.perf_counter() - t1) / args.steps
+        assert np.array_equal(out_host, out), "host-buffer and device-buffer calls disagree"
         # kernel times: one more call with the launches bracketed by HIP events on the handle's stream
         dec.configure(timing=1)
-        dec.min_sum_batch(*inputs)
+        step()
         kt = dec.last_timing()
         dec.configure(timing=0)
     per_rank_ms = None
@@ -615,9 +634,11 @@ def qary_bench(args, S, rank, world, dist, backend, local, iters):
             "unit": "directed symbol-edge message updates/s", "n_gpus": world, "steps": args.steps, "warmup": max(1, args.warmup),
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{what}, {iters} iterations, batch {batch}/GPU, host pmf in / symbols out (PCIe included; "
-                                   f"probability->LLR conversion on the device)", "batch_per_gpu": batch, "iters": iters},
+            "config": {"workload": f"{what}, {iters} iterations, batch {batch}/GPU, pmf resident in HBM / symbols left in HBM "
+                                   f"(probability->LLR conversion on the device, inside the timed call)", "batch_per_gpu": batch, "iters": iters},
             "codewords_per_s": batch * args.steps * world / dt, "calls_per_s": args.steps * world / dt,
+            "host_buffers": {"ms_per_step": dt_host * 1e3, "value": 2.0 * g.nnz * batch * iters / dt_host,
+                             "what": "the same call with host arrays in and out, as the PyO3 class takes them (PCIe both ways included)"},
             "all_zero_rate": float((out == 0).all(axis=1).mean()),
             "kernel_ms": {"check_per_launch": ms_check, "var_per_launch": kt["ms_var"] / kt["iterations"],
                           "iteration_loop": kt["ms_loop"]},

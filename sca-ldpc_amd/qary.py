@@ -97,6 +97,12 @@ class QaryDecoder(_QaryBase):
         _lib.check(self._lib.scaldpc_qary_min_sum_batch(self._h, _lib.ptr(p), p.shape[0], 0, None, _lib.ptr(out)))
         return out
 
+    def min_sum_batch_device(self, d_channel_output, batch, d_out, stream=0):
+        """Device-pointer variant (ints, e.g. torch `tensor.data_ptr()`): float32 [batch, N, Q] probabilities in HBM ->
+        int8 [batch, N] in HBM; nothing crosses PCIe.  Returns after the stream work is complete."""
+        _lib.check(self._lib.scaldpc_qary_min_sum_batch(self._h, C.c_void_p(d_channel_output), int(batch), _lib.F_DEVICE_IO,
+                                                        C.c_void_p(stream or None), C.c_void_p(d_out)))
+
     def min_sum(self, py_channel_output):
         p = np.asarray(py_channel_output)
         if p.shape != (self.N, self.Q):
@@ -131,6 +137,12 @@ class QarySpecialDecoder(_QaryBase):
             self._lib.scaldpc_qary_special_min_sum_batch(self._h, _lib.ptr(p), _lib.ptr(ps), p.shape[0], 0, None, _lib.ptr(out))
         )
         return out
+
+    def min_sum_batch_device(self, d_channel_output, d_channel_output_sum, batch, d_out, stream=0):
+        """Device-pointer variant: float32 [batch, N-R, 2B+1] and [batch, R, 2BSUM+1] in HBM -> int8 [batch, N] in HBM."""
+        _lib.check(self._lib.scaldpc_qary_special_min_sum_batch(self._h, C.c_void_p(d_channel_output), C.c_void_p(d_channel_output_sum),
+                                                                int(batch), _lib.F_DEVICE_IO, C.c_void_p(stream or None),
+                                                                C.c_void_p(d_out)))
 
     def min_sum(self, py_channel_output, py_channel_output_sum):
         p, ps = np.asarray(py_channel_output), np.asarray(py_channel_output_sum)

@@ -288,3 +288,33 @@ def test_special_tree_kernel_with_mixed_row_degrees_and_impossible_symbols(oracl
             out[name] = dec.min_sum_batch(pb, ps)
     for name, o in out.items():
         assert np.array_equal(o, ref), name
+
+
+def test_device_pointer_calls_equal_host_buffer_calls(oracle, golden):
+    """SCALDPC_F_DEVICE_IO on both q-ary entry points (what bench.py times: channel outputs resident in HBM, symbols
+    left in HBM): same symbols as the host-buffer call and as the oracle, on the caller's stream; a ragged batch
+    (not a multiple of 64) and a second call with a smaller batch on the same handle."""
+    import torch
+
+    g = S.TannerGraph.from_coo(golden["generators"]["regular_identity_300_150_3_6_s1"])
+    dec = qary.decoder_class("DecoderN450R150V3C7B1")(g.to_dense(np.int8), 5)
+    rng = np.random.RandomState(77)
+    pmf = rng.dirichlet(np.ones(3) * 3, size=(300, 450)).astype(np.float32)
+    stream = torch.cuda.current_stream().cuda_stream
+    for nb in (300, 70):
+        d_in = torch.from_numpy(pmf[:nb]).cuda()
+        d_out = torch.full((nb, 450), 99, dtype=torch.int8, device="cuda")
+        dec.min_sum_batch_device(d_in.data_ptr(), nb, d_out.data_ptr(), stream=stream)
+        got = d_out.cpu().numpy()
+        assert np.array_equal(got, dec.min_sum_batch(pmf[:nb]))
+        assert np.array_equal(got, oracle.qary_min_sum_batch(g, 3, pmf[:nb], 5, threads=8))
+    dec.close()
+    gk = S.TannerGraph.from_coo(golden["generators"]["qary_qc_256_6_3_s0_cb2"])
+    deck = qary.decoder_class("DecoderN1280R512SW6")(gk.to_dense(np.int8), 2)
+    pb = rng.dirichlet(np.ones(5), size=(5, 768)).astype(np.float32)
+    ps = rng.dirichlet(np.ones(25), size=(5, 512)).astype(np.float32)
+    d_b, d_s = torch.from_numpy(pb).cuda(), torch.from_numpy(ps).cuda()
+    d_out = torch.full((5, 1280), 99, dtype=torch.int8, device="cuda")
+    deck.min_sum_batch_device(d_b.data_ptr(), d_s.data_ptr(), 5, d_out.data_ptr(), stream=stream)
+    assert np.array_equal(d_out.cpu().numpy(), oracle.qary_special_batch(gk, 2, 12, pb, ps, 2, threads=8))
+    deck.close()
