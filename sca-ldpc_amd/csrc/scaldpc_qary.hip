@@ -128,6 +128,10 @@ __global__ void k_q_init(const int *__restrict__ edge_var, const int *__restrict
 // Check-node update of Decoder (decoder.rs:585-631), finite-support enumeration
 // (FiniteDValueIterator, decoder.rs:281-401), index 0 fastest.
 // block = T threads = T codewords of one check; LDS: A[k*Q][T], Bt[k*Q][T] floats, fin[k*Q][T] bytes.
+// WORD: the per-lane registers that hold one 8-bit digit per edge of the check (finite-symbol counts, the
+// enumeration index, the chosen symbols): u64 for checks of up to 8 edges (every size the reference registers,
+// lib.rs:32-75), unsigned __int128 for 9..16 -- Decoder is const-generic in DC (decoder.rs:417-438).
+template <typename WORD>
 __global__ void k_q_check(const int *__restrict__ row_ptr, float *msg, int Q, int B, long Bp, int batch, int maxdc,
                           int *__restrict__ err)
 {
@@ -144,7 +148,7 @@ __global__ void k_q_check(const int *__restrict__ row_ptr, float *msg, int Q, in
         if (tid == 0) atomicMax(err, QERR_NO_CONFIG);
         return;
     }
-    u64 nums = 0;
+    WORD nums = 0;
     bool bad = false;
     for (int j = 0; j < k; j++) {
         int cnt = 0;
@@ -154,29 +158,29 @@ __global__ void k_q_check(const int *__restrict__ row_ptr, float *msg, int Q, in
             Bt[(size_t)(j * Q + q) * T + tid] = INFINITY;
             if (finite_f(x)) fin[(size_t)(j * Q + cnt++) * T + tid] = (unsigned char)q;
         }
-        nums |= (u64)cnt << (8 * j);
+        nums |= (WORD)cnt << (8 * j);
         bad |= cnt == 0;
     }
     if (bad) {
         atomicMax(err, QERR_NO_FINITE);
     } else {
-        u64 idx = 0;
+        WORD idx = 0;
         int nconf = 0;
         for (;;) {
             int dsum = 0;
             float S = 0.0f;
-            u64 qs = 0;
+            WORD qs = 0;
             for (int j = 0; j < k - 1; j++) {
                 const int ij = (int)(idx >> (8 * j)) & 255;
                 const int q = fin[(size_t)(j * Q + ij) * T + tid];
-                qs |= (u64)q << (8 * j);
+                qs |= (WORD)q << (8 * j);
                 dsum += q - B;
                 S += A[(size_t)(j * Q + q) * T + tid];
             }
             const int dl = -dsum;
             if (dl >= -B && dl <= B) {
                 const int ql = dl + B;
-                qs |= (u64)ql << (8 * (k - 1));
+                qs |= (WORD)ql << (8 * (k - 1));
                 S += A[(size_t)((k - 1) * Q + ql) * T + tid];
                 if (finite_f(S)) {
                     nconf++;
@@ -191,10 +195,10 @@ __global__ void k_q_check(const int *__restrict__ row_ptr, float *msg, int Q, in
             for (; j < k - 1; j++) {
                 const int ij = (int)(idx >> (8 * j)) & 255, nj = (int)(nums >> (8 * j)) & 255;
                 if (ij + 1 < nj) {
-                    idx += 1ull << (8 * j);
+                    idx += (WORD)1 << (8 * j);
                     break;
                 }
-                idx &= ~(255ull << (8 * j));
+                idx &= ~((WORD)255 << (8 * j));
             }
             if (j >= k - 1) break;
         }
@@ -815,7 +819,10 @@ int qary_build(int R, int N, int B, int BSUM, bool special, const int8_t *H, int
     const int E = (int)edge_var.size();
     int maxdc = 0;
     for (int r = 0; r < R; r++) maxdc = std::max(maxdc, row_ptr[r + 1] - row_ptr[r]);
-    if (maxdc > 8) return fail(SCALDPC_EDEGREE, "check degree %d > 8 is not supported by the enumeration kernel", maxdc);
+    // one 8-bit digit per edge of a check in a register word: 64 bits for degree <= 8 (all kernels), 128 bits for 9..16
+    // (the lane-per-codeword kernel only: Decoder is const-generic in DC, decoder.rs:417-438; the reference registers 4 and 7)
+    if (maxdc > (special ? 8 : 16))
+        return fail(SCALDPC_EDEGREE, "check degree %d > %d is not supported by the enumeration kernels", maxdc, special ? 8 : 16);
     if (special) {
         for (int r = 0; r < R; r++) {
             const int k = row_ptr[r + 1] - row_ptr[r];
@@ -965,6 +972,7 @@ int qary_run(scaldpc_qary *h, const float *pmf_b, const float *pmf_s, int batch,
     // every batch size measured (93 vs 153 ms at batch 256)
     bool wave_mode = (batch <= 256 || h->special) && wave_lds <= 64 * 1024;
     if (h->kn_wave >= 0) wave_mode = h->kn_wave != 0 && wave_lds <= 64 * 1024;
+    if (h->maxdc > 8) wave_mode = false;  // 64-bit digit words in the wave kernels
     // small alphabets: fully unrolled register enumeration (any batch size)
     int unrolled = 0;
     if (!h->special && h->kn_unroll) {
@@ -1012,8 +1020,12 @@ int qary_run(scaldpc_qary *h, const float *pmf_b, const float *pmf_s, int batch,
                 hipLaunchKernelGGL(k_q_special_check, dim3(h->R, Bp / T), dim3(T), per_thread * T, s, h->d_row_ptr,
                                    h->d_msg, h->B, h->BSUM, h->W, Bp, batch, h->maxdc - 1);
             else
-                hipLaunchKernelGGL(k_q_check, dim3(h->R, Bp / T), dim3(T), per_thread * T, s, h->d_row_ptr, h->d_msg,
-                                   h->Q, h->B, Bp, batch, h->maxdc, h->d_err);
+                if (h->maxdc <= 8)
+                    hipLaunchKernelGGL(k_q_check<u64>, dim3(h->R, Bp / T), dim3(T), per_thread * T, s, h->d_row_ptr, h->d_msg,
+                                       h->Q, h->B, Bp, batch, h->maxdc, h->d_err);
+                else
+                    hipLaunchKernelGGL(k_q_check<unsigned __int128>, dim3(h->R, Bp / T), dim3(T), per_thread * T, s, h->d_row_ptr,
+                                       h->d_msg, h->Q, h->B, Bp, batch, h->maxdc, h->d_err);
             SC_HIP(hipGetLastError());
         }
         if (timing) SC_HIP(hipEventRecord(h->tev[2 * (it - 1) + 1], s));

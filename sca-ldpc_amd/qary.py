@@ -164,16 +164,20 @@ def into_llr(channel_output):
     return out
 
 
-MAX_CHECK_DEGREE = 8  # the enumeration kernels pack one 8-bit digit per edge of a check into a 64-bit word
+# the enumeration kernels pack one 8-bit digit per edge of a check into a register word: 64 bits in every kernel
+# (degree <= 8: all sizes the reference registers), 128 bits in the lane-per-codeword kernel of the plain decoder (<= 16)
+MAX_CHECK_DEGREE = 16
+MAX_SPECIAL_CHECK_DEGREE = 8
 
 
-def _check_limits(name, DC, B, BSUM):
+def _check_limits(name, DC, B, BSUM, special=False):
     """The reference generates a class per registered size (lib.rs:32-75: DC = 4, 7, 7, 7) and a name it
     has not registered is an AttributeError on `getattr(simulate_rs, name)` (decode.py:227-229).  Here
     any size resolves -- up to what the kernels are built for; beyond that the name does not resolve
     either, with the reason, at look-up time rather than at the first construction."""
-    if DC > MAX_CHECK_DEGREE:
-        raise AttributeError(f"{name}: check degree {DC} > {MAX_CHECK_DEGREE} is not supported by the enumeration kernels "
+    lim = MAX_SPECIAL_CHECK_DEGREE if special else MAX_CHECK_DEGREE
+    if DC > lim:
+        raise AttributeError(f"{name}: check degree {DC} > {lim} is not supported by the enumeration kernels "
                              f"(scaldpc_qary.hip; the reference's registered sizes use 4 and 7)")
     if B > 127 or BSUM > 127:
         raise AttributeError(f"{name}: symbols beyond +-127 do not fit the int8 hard decisions (decoder.rs i8)")
@@ -197,7 +201,7 @@ def decoder_class(name: str):
             raise AttributeError(name)
         N, R, SW = map(int, m.groups())
         B = 2  # Kyber eta (lib.rs:54-75: B = 2, BSUM = SW * B)
-        _check_limits(name, SW + 1, B, SW * B)
+        _check_limits(name, SW + 1, B, SW * B, special=True)
         cls = type(
             name, (QarySpecialDecoder,),
             dict(N=N, R=R, DV=R, DC=SW + 1, B=B, Q=2 * B + 1, BSUM=SW * B, QS=2 * SW * B + 1),

@@ -318,3 +318,29 @@ def test_device_pointer_calls_equal_host_buffer_calls(oracle, golden):
     deck.min_sum_batch_device(d_b.data_ptr(), d_s.data_ptr(), 5, d_out.data_ptr(), stream=stream)
     assert np.array_equal(d_out.cpu().numpy(), oracle.qary_special_batch(gk, 2, 12, pb, ps, 2, threads=8))
     deck.close()
+
+
+def test_check_degree_beyond_eight(oracle):
+    """Decoder is const-generic in DC (decoder.rs:417-438); the reference registers DC = 4 and 7 (lib.rs:32-75).  Checks of
+    9..16 edges run on the lane-per-codeword kernel with 128-bit digit words: same symbols as the oracle; 17 edges do not
+    resolve (AttributeError at look-up, as an unregistered size does in the reference, decode.py:227-229)."""
+    rng = np.random.RandomState(12)
+    R, N, B = 6, 40, 1
+    H = np.zeros((R, N), dtype=np.int8)
+    for r, k in enumerate((9, 10, 12, 3, 9, 11)):
+        H[r, rng.choice(N, k, replace=False)] = rng.choice([-1, 1], size=k)
+    g = S.TannerGraph.from_dense(H)
+    pmf = rng.dirichlet(np.ones(3) * 2, size=(70, N)).astype(np.float32)
+    pmf[:, ::9, 2] = 0.0  # some +inf costs: finite supports of different sizes
+    pmf /= pmf.sum(axis=2, keepdims=True)
+    name = f"DecoderN{N}R{R}V{int(g.col_degrees().max())}C12B{B}"
+    dec = qary.decoder_class(name)(H, 3)
+    with np.errstate(divide="ignore"):
+        got = dec.min_sum_batch(pmf)
+        ref = oracle.qary_min_sum_batch(g, 3, pmf, 3, threads=8)
+    dec.close()
+    assert np.array_equal(got, ref)
+    with pytest.raises(AttributeError, match="check degree 17"):
+        qary.decoder_class("DecoderN40R6V3C17B1")
+    with pytest.raises(AttributeError, match="check degree 9"):
+        qary.decoder_class("DecoderN40R6SW8")  # DecoderSpecial: DC = SW + 1 = 9 > 8
