@@ -174,7 +174,8 @@ int scaldpc_bp_last_compacted(scaldpc_bp *h, int64_t *count);
 int scaldpc_bp_last_stats(scaldpc_bp *h, int64_t *out);
 /* Tuning / test knobs of one handle.  A new handle takes its defaults from the environment ONCE, at
  * creation (SCALDPC_PATH, SCALDPC_SPLIT, SCALDPC_GROUP_MB, SCALDPC_EL_MAX, SCALDPC_EL_FUSE,
- * SCALDPC_COMPACT_AFTER, SCALDPC_MINSUM_LOOP, SCALDPC_VAR_ORDER, SCALDPC_VAR_FORM, SCALDPC_SPECULATE); the
+ * SCALDPC_COMPACT_AFTER, SCALDPC_MINSUM_LOOP, SCALDPC_VAR_ORDER, SCALDPC_VAR_FORM, SCALDPC_SPECULATE,
+ * SCALDPC_FUSE_FINALIZE, SCALDPC_TEST_OVERLAP); the
  * decode entry points never read
  * the environment.  key / value (text):
  *   "path"          "auto" | "stream" (64-codeword tiles) | "edge" (row-parallel up to 64) | "lds"
@@ -193,7 +194,10 @@ int scaldpc_bp_last_stats(scaldpc_bp *h, int64_t *out);
  *                   device once two groups in a row handed a small remainder to the compact pass there,
  *                   0 = every group polls
  *   "fuse_finalize" 1 (default) = convergence test and latch of the tile early-exit loop in one launch,
- *                   0 = two launches.  Results never depend on any of these. */
+ *                   0 = two launches.
+ *   "test_overlap"  1 (default) = that launch runs on a side stream of its lane, beside the check pass of the next
+ *                   iteration (it feeds only the next VARIABLE pass), 0 = in line (SCALDPC_TEST_OVERLAP).
+ *   Results never depend on any of these. */
 int scaldpc_bp_configure(scaldpc_bp *h, const char *key, const char *value);
 /* Where a handle lives, out[4]: the device it was created on; the device (hipPointerGetAttributes)
  * of its graph allocation, of its message workspace and of its state planes (-1 = not allocated yet).

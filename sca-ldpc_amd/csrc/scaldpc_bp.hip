@@ -73,6 +73,7 @@ struct Knobs {
     int var_order = -1;       // k_var launch order: bit 0 = inside a degree by first edge id, bit 1 = heaviest columns first; -1 = auto
     int fuse_finalize = 1;    // tile early-exit loop: convergence test and latch in one launch (k_parity_fin); 0 = k_parity + k_finalize
     int speculate = 1;        // early-exit tile groups: stop at the hand-over point without polling once two groups in a row did (0 = always poll)
+    int test_overlap = 1;     // early-exit tile groups: the convergence test of iteration it runs on a side stream beside the check pass of it + 1
     int var_form = 1;         // k_var: 0 = ids fetched edge by edge, 1 = all ids up front as wide scalar loads (default)
 };
 
@@ -171,6 +172,8 @@ struct scaldpc_bp {
     int device = 0;  // the device the handle (and its stream) was created on
     hipStream_t aux_stream[4] = {};  // further lanes of a tile group (iterate_tiles)
     hipEvent_t ev_join[4] = {}, ev_phase[4] = {};
+    hipStream_t test_stream[4] = {};  // per lane: the side stream of the overlapped convergence test (iterate_tiles)
+    hipEvent_t ev_var[4] = {}, ev_test[4] = {};  // "variable pass of the lane enqueued" / "its convergence test enqueued"
     // Set by the first SCALDPC_F_ASYNC call and never cleared: work may be in flight when a later call
     // (or destroy) releases a buffer, so this handle's blocks go back through hipFree (which
     // waits for the device) instead of being parked for immediate reuse.
@@ -209,6 +212,7 @@ bool set_knob(Knobs &k, const char *key, const char *val)
     else if (!strcmp(key, "var_form")) k.var_form = (int)x;
     else if (!strcmp(key, "speculate")) k.speculate = (int)x != 0;
     else if (!strcmp(key, "fuse_finalize")) k.fuse_finalize = (int)x != 0;
+    else if (!strcmp(key, "test_overlap")) k.test_overlap = (int)x != 0;
     else return false;
     return true;
 }
@@ -218,7 +222,7 @@ void knobs_from_env(Knobs &k)
     static const char *const names[][2] = {{"SCALDPC_PATH", "path"}, {"SCALDPC_SPLIT", "split"},
                                            {"SCALDPC_GROUP_MB", "group_mb"}, {"SCALDPC_EL_MAX", "el_max"},
                                            {"SCALDPC_EL_FUSE", "el_fuse"}, {"SCALDPC_COMPACT_AFTER", "compact_after"},
-                                           {"SCALDPC_VAR_ORDER", "var_order"}, {"SCALDPC_VAR_FORM", "var_form"}, {"SCALDPC_SPECULATE", "speculate"}, {"SCALDPC_FUSE_FINALIZE", "fuse_finalize"}};
+                                           {"SCALDPC_VAR_ORDER", "var_order"}, {"SCALDPC_VAR_FORM", "var_form"}, {"SCALDPC_SPECULATE", "speculate"}, {"SCALDPC_FUSE_FINALIZE", "fuse_finalize"}, {"SCALDPC_TEST_OVERLAP", "test_overlap"}};
     for (auto &nm : names)
         if (const char *e = getenv(nm[0])) (void)set_knob(k, nm[1], e);
     if (getenv("SCALDPC_MINSUM_LOOP")) k.minsum_loop = 1;  // presence switches it on, as before
@@ -796,6 +800,17 @@ int ensure_lanes(scaldpc_bp *h, int nl)
     if (nl > 1 && !h->ev_join[0]) SC_HIP(hipEventCreateWithFlags(&h->ev_join[0], hipEventDisableTiming));  // [0]: the fork event
     return 0;
 }
+int ensure_test_streams(scaldpc_bp *h, int nl)
+{
+    for (int k = 0; k < nl; k++)
+        if (!h->test_stream[k]) {
+            int dev = 0;
+            SC_TRY(stream_acquire(&h->test_stream[k], &dev));
+            SC_HIP(hipEventCreateWithFlags(&h->ev_var[k], hipEventDisableTiming));
+            SC_HIP(hipEventCreateWithFlags(&h->ev_test[k], hipEventDisableTiming));
+        }
+    return 0;
+}
 // What the groups of one call learn from each other about polling (a poll drains the queue: the GPU idles
 // while the host turns around, ~4 % of a group's time on the config-5 sweep):
 //   hint   poll points before this iteration saw no codeword finish in earlier groups: skip them
@@ -838,7 +853,25 @@ int iterate_tiles(scaldpc_bp *h, const TileState &st, int g0, int g, int max_ite
         SC_HIP(hipEventRecord(h->ev_join[0], s));
         for (int k = 1; k < nl; k++) SC_HIP(hipStreamWaitEvent(lane[k], h->ev_join[0], 0));
     }
+    // Early-exit runs: the convergence test of iteration it (k_parity_fin: reads the decisions the variable pass just
+    // wrote, latches done / conv / iters) does not feed the check pass of iteration it + 1 (messages only), so it runs on
+    // a side stream of its lane BESIDE that check pass; the lane waits for it before its next variable pass, the first
+    // reader of the `done` mask that matters.  (The check pass reads `done` only to skip a tile that is frozen as a
+    // whole: if it races with the latch that freezes the tile, some of its rows update messages nobody reads again.)
+    // The test is latency-bound (15 us per launch, 12 % of the GPU time of the config-5 sweep when serialised) and
+    // moves 2 % of a check pass's bytes.
+    const bool ovl = early && h->kn.fuse_finalize && h->kn.test_overlap && h->E > 0;
+    if (ovl) SC_TRY(ensure_test_streams(h, nl));
+    bool test_pending[MAX_LANES] = {};
+    auto wait_test = [&](int k) -> int {  // lane k goes on only after its convergence test in flight
+        if (test_pending[k]) {
+            SC_HIP(hipStreamWaitEvent(lane[k], h->ev_test[k], 0));
+            test_pending[k] = false;
+        }
+        return 0;
+    };
     auto join = [&]() -> int {
+        for (int k = 0; k < nl; k++) SC_TRY(wait_test(k));
         for (int k = 1; k < nl; k++) {
             SC_HIP(hipEventRecord(h->ev_join[k], lane[k]));
             SC_HIP(hipStreamWaitEvent(s, h->ev_join[k], 0));
@@ -860,14 +893,25 @@ int iterate_tiles(scaldpc_bp *h, const TileState &st, int g0, int g, int max_ite
         set_phase = false;
         for (int k = 0; k < nl; k++) {
             const int ta = g0 + t0[k];
+            SC_TRY(wait_test(k));  // the test of the previous iteration decides which codewords this pass may still write
             SC_TRY(launch_var(h, gs[k], st.post ? st.post + (size_t)ta * h->n * TW : nullptr, st.hard + (size_t)ta * h->n,
                               st.done + ta, skip, (early || last) ? 1 : 0, lane[k], t0[k]));
             if ((early || last) && h->kn.fuse_finalize) {  // convergence test + latch, one launch
+                hipStream_t ts = lane[k];
+                if (ovl) {
+                    ts = h->test_stream[k];
+                    SC_HIP(hipEventRecord(h->ev_var[k], lane[k]));
+                    SC_HIP(hipStreamWaitEvent(ts, h->ev_var[k], 0));
+                }
                 hipLaunchKernelGGL(k_parity_fin, dim3((h->m + 4 * ROWS_PER_WAVE - 1) / (4 * ROWS_PER_WAVE), gs[k]), dim3(256), 0,
-                                   lane[k], h->d_row_ptr, h->d_col_idx, st.hard + (size_t)ta * h->n, h->m, h->n,
+                                   ts, h->d_row_ptr, h->d_col_idx, st.hard + (size_t)ta * h->n, h->m, h->n,
                                    st.synd + (size_t)ta * h->m, st.unsat + (size_t)ta * pw, pw, it, early ? 1 : 0, st.done + ta,
                                    st.conv + ta, st.iters + (size_t)ta * TW, h->d_remaining + it);
                 LAUNCH_CHECK();
+                if (ovl) {
+                    SC_HIP(hipEventRecord(h->ev_test[k], ts));
+                    test_pending[k] = true;
+                }
             } else if (early || last) {
                 hipLaunchKernelGGL(k_parity<true>, dim3((h->m + 4 * ROWS_PER_WAVE - 1) / (4 * ROWS_PER_WAVE), gs[k]), dim3(256),
                                    0, lane[k], h->d_row_ptr, h->d_col_idx, st.hard + (size_t)ta * h->n, h->m, h->n,
@@ -2118,6 +2162,9 @@ void scaldpc_bp_destroy(scaldpc_bp *h)
         if (h->aux_stream[k]) stream_release(h->aux_stream[k], h->device);
         if (h->ev_join[k]) (void)hipEventDestroy(h->ev_join[k]);
         if (h->ev_phase[k]) (void)hipEventDestroy(h->ev_phase[k]);
+        if (h->test_stream[k]) stream_release(h->test_stream[k], h->device);
+        if (h->ev_var[k]) (void)hipEventDestroy(h->ev_var[k]);
+        if (h->ev_test[k]) (void)hipEventDestroy(h->ev_test[k]);
     }
     delete h;
 }
