@@ -106,12 +106,16 @@ def compare(got, ref, method, llr_rtol=2e-4, llr_atol=2e-4, widened_tol=None, ti
         assert (~decided)[conv].sum() <= max(3, 1e-3 * decided[conv].size), "ties on converged trials"
 
 
-def compare_with_reference_form(got, ref64, tol=1e-3, clamp=30.0):
+def compare_with_reference_form(got, ref64, tol=1e-3, clamp=24.0):
     """HIP fp32 tanh rule vs the float64 probability-ratio recursion the reference's
     package runs ("product_sum", oracle method 0).  Stated fp32 tolerance (SURVEY.md
-    App. A): after clamping |L| <= 30, |dL| <= 1e-3 * max(1, |L|); hard decisions
+    App. A): after clamping, |dL| <= 1e-3 * max(1, |L|); hard decisions
     exact wherever the reference's |L| exceeds that tolerance.  (inf - inf = NaN posteriors, which
-    +-inf priors can produce on both sides, must sit in the same places.)"""
+    +-inf priors can produce on both sides, must sit in the same places.)
+    The clamp is 24, not the 30 SURVEY suggested: the ratio form computes 1 - t as 2 / (1 + r) - 1 with
+    r = e^-|L|, which in float64 is good to 1e-16 * e^|L| per factor -- 1e-6 at |L| = 24 but 1e-3 at |L| = 30
+    times the row degree.  Measured (round 3): at L = -27.06 the float64 LLR-domain forms and the device agree
+    to 1e-7 while the ratio form itself is off by 0.036; beyond the clamp both sides just say "certain"."""
     a = np.clip(got["llr"].astype(np.float64), -clamp, clamp)
     b = np.clip(ref64["llr"], -clamp, clamp)
     nan = np.isnan(b)
