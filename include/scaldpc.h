@@ -195,8 +195,9 @@ int scaldpc_bp_last_stats(scaldpc_bp *h, int64_t *out);
  *                   0 = every group polls
  *   "fuse_finalize" 1 (default) = convergence test and latch of the tile early-exit loop in one launch,
  *                   0 = two launches.
- *   "test_overlap"  1 (default) = that launch runs on a side stream of its lane, beside the check pass of the next
- *                   iteration (it feeds only the next VARIABLE pass), 0 = in line (SCALDPC_TEST_OVERLAP).
+ *   "test_overlap"  1 = that launch runs on a side stream of its lane, beside the check pass of the next iteration
+ *                   (it feeds only the next VARIABLE pass), 0 (default) = in line (SCALDPC_TEST_OVERLAP; measured
+ *                   3.4 % slower on the config-5 sweep, kept for the record).
  *   Results never depend on any of these. */
 int scaldpc_bp_configure(scaldpc_bp *h, const char *key, const char *value);
 /* Where a handle lives, out[4]: the device it was created on; the device (hipPointerGetAttributes)

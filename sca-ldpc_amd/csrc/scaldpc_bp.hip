@@ -73,7 +73,7 @@ struct Knobs {
     int var_order = -1;       // k_var launch order: bit 0 = inside a degree by first edge id, bit 1 = heaviest columns first; -1 = auto
     int fuse_finalize = 1;    // tile early-exit loop: convergence test and latch in one launch (k_parity_fin); 0 = k_parity + k_finalize
     int speculate = 1;        // early-exit tile groups: stop at the hand-over point without polling once two groups in a row did (0 = always poll)
-    int test_overlap = 1;     // early-exit tile groups: the convergence test of iteration it runs on a side stream beside the check pass of it + 1
+    int test_overlap = 0;     // early-exit tile groups: 1 = the convergence test of iteration it runs on a side stream beside the check pass of it + 1 (A/B knob: measured 3.4 % SLOWER on the config-5 sweep, profiles/r03/ab_test_overlap.log)
     int var_form = 1;         // k_var: 0 = ids fetched edge by edge, 1 = all ids up front as wide scalar loads (default)
 };
 
@@ -859,7 +859,10 @@ int iterate_tiles(scaldpc_bp *h, const TileState &st, int g0, int g, int max_ite
     // reader of the `done` mask that matters.  (The check pass reads `done` only to skip a tile that is frozen as a
     // whole: if it races with the latch that freezes the tile, some of its rows update messages nobody reads again.)
     // The test is latency-bound (15 us per launch, 12 % of the GPU time of the config-5 sweep when serialised) and
-    // moves 2 % of a check pass's bytes.
+    // moves 2 % of a check pass's bytes -- and still the overlap does not pay: 366 k trials/s against 379 k in line
+    // (two runs each, identical results, profiles/r03/ab_test_overlap.log).  Two lanes already keep the fabric
+    // saturated, so the test's gathers are not free beside a check pass, and the two extra event hops per iteration
+    // and lane lengthen the dependency chain.  Kept as an A/B knob, OFF by default.
     const bool ovl = early && h->kn.fuse_finalize && h->kn.test_overlap && h->E > 0;
     if (ovl) SC_TRY(ensure_test_streams(h, nl));
     bool test_pending[MAX_LANES] = {};
