@@ -15,6 +15,16 @@ pytestmark = pytest.mark.gpu
 bp = importlib.import_module("sca-ldpc_amd.bp")
 
 
+_examples = [0]
+
+
+def _progress():
+    """A line every 25 examples (long soak runs, SCALDPC_PROPERTY_EXAMPLES=500: a GPU box takes minutes of silence for a hang)."""
+    _examples[0] += 1
+    if _examples[0] % 25 == 0:
+        print(f"[property examples: {_examples[0]}]", flush=True)
+
+
 def _own_sensitivity(oracle, g, probs, x, kind, max_iter, method, early, ref):
     """20x the largest relative move of the oracle's posteriors between float32 and float64 (same
     operation order), never below the fixed fp32 tolerance 2e-4."""
@@ -44,6 +54,7 @@ def _own_sensitivity(oracle, g, probs, x, kind, max_iter, method, early, ref):
 )
 def test_random_instances(oracle, m, n, density, batch, method, received, early, path, max_iter, seed, inf_priors, lanes,
                           group):
+    _progress()
     if m == n:
         n += 1  # square H needs an explicit input type; covered elsewhere
     if method == "product_sum":
@@ -115,6 +126,7 @@ def test_random_hqc_shaped_instances(oracle, N, W, rfrac, omega, eps, batch, met
     tests/test_bp_gpu.py the fixed tolerance holds without it."""
     from helpers import hqc_instance
 
+    _progress()
     R = max(20, int(N * rfrac))
     H, Hin, probs, msg, y = hqc_instance(N, W, R, omega, eps, batch, seed=seed)
     env = {"SCALDPC_SPLIT": str(lanes)}
