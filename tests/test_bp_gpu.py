@@ -322,6 +322,47 @@ def test_hqc256_bench_configuration(oracle, decode_path):
 
 
 @pytest.mark.parametrize("method", ["min_sum", "product_sum"])
+def test_full_size_invariances(method, decode_path):
+    """Size-independent properties at BASELINE config 2's full size (HQC-128 graph, batch 4096, no oracle needed):
+      * a codeword's result does not depend on WHERE in the batch it sits (tile, lane, stream lane, tile group):
+        decoding the batch in reversed order gives the reversed results, bit for bit, posteriors included;
+      * received-vector mode is syndrome mode: decode(v) == decode_syndrome(H v) XOR v, same posteriors, same counts;
+      * flags are truthful: every codeword flagged converged satisfies H e == s, iteration counts lie in [1, max_iter],
+        and a codeword converged at iteration k < max_iter was not touched afterwards (its early-exit result equals the
+        result of a run capped at k iterations)."""
+    if decode_path != "auto":
+        pytest.skip("the library's own schedule at full size")
+    import json, os
+
+    trials = importlib.import_module("sca-ldpc_amd.trials")
+    rows = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "hqc_first_rows.json")))
+    H, Hin, _ = S.codes.hqc_bench_graph("hqc128", rows["N17669_W50_s0"])
+    N, omega = S.codes.HQC_PARAMS["hqc128"]
+    eps, batch, iters = 0.05, 4096, 20
+    probs = trials.hqc_priors(N, Hin.m, omega, eps)
+    msg, ys = trials.hqc_trials(Hin, omega, eps, batch, base_seed=9, first_index=0)
+    dec = bp.bp_decoder(H, max_iter=iters, bp_method=method, channel_probs=probs)
+    a = dec.decode_batch(msg, early_exit=True, want_llr=True)
+    b = dec.decode_batch(msg[::-1], early_exit=True, want_llr=True)
+    for k in ("bits", "llr", "iters", "converged"):
+        assert np.array_equal(a[k], b[k][::-1]), f"batch position changes {k}"
+    synd = H.syndrome(msg)
+    c = dec.decode_batch(synd, early_exit=True, want_llr=True, input_vector_type="syndrome")
+    assert np.array_equal(c["bits"] ^ msg, a["bits"]) and np.array_equal(c["iters"], a["iters"])
+    assert np.array_equal(c["llr"], a["llr"]) and np.array_equal(c["converged"], a["converged"])
+    conv = a["converged"].astype(bool)
+    assert np.array_equal(H.syndrome(c["bits"][conv]), synd[conv]) and 0.5 < conv.mean() <= 1.0
+    assert a["iters"].min() >= 1 and a["iters"].max() <= iters and (a["iters"][~conv] == iters).all()
+    k = int(np.median(a["iters"][conv]))
+    capped = dec.decode_batch(msg, max_iter=k, early_exit=True, want_llr=True)
+    early = conv & (a["iters"] <= k)
+    assert early.sum() > 100
+    assert np.array_equal(capped["bits"][early], a["bits"][early]) and np.array_equal(capped["llr"][early], a["llr"][early])
+    assert np.array_equal(capped["iters"][early], a["iters"][early])
+    dec.close()
+
+
+@pytest.mark.parametrize("method", ["min_sum", "product_sum"])
 def test_straggler_compaction_is_invisible(oracle, method, monkeypatch, decode_path):
     """Early-exit runs re-decode the stragglers of mostly-converged tile groups in a compact
     second pass.  Results (decisions, posteriors, iteration counts, flags) must be identical
