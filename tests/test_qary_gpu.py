@@ -344,3 +344,30 @@ def test_check_degree_beyond_eight(oracle):
         qary.decoder_class("DecoderN40R6V3C17B1")
     with pytest.raises(AttributeError, match="check degree 9"):
         qary.decoder_class("DecoderN40R6SW8")  # DecoderSpecial: DC = SW + 1 = 9 > 8
+
+
+def test_full_size_invariances(golden):
+    """Size-independent properties at BASELINE config 4's full size (150 x 450, Q = 3, batch 1024, 5 iterations) and on the
+    Kyber shape: a codeword's symbols do not depend on where in the batch it sits (lane, block, wave mode vs lane mode),
+    and an error-free channel output (every variable's pmf peaked at 0) decodes to the all-zero word."""
+    g = S.TannerGraph.from_coo(golden["generators"]["regular_identity_300_150_3_6_s1"])
+    dec = qary.decoder_class("DecoderN450R150V3C7B1")(g.to_dense(np.int8), 5)
+    rng = np.random.RandomState(404)
+    p = 1 / 3
+    good, bad = np.array([p, 1.75 * p, 0.25 * p]), np.array([p, 0.25 * p, 1.75 * p])
+    pmf = np.where((rng.rand(1024, 450) < 0.02)[:, :, None], bad, good).astype(np.float32)
+    pmf[7] = good
+    a = dec.min_sum_batch(pmf)
+    assert np.array_equal(dec.min_sum_batch(pmf[::-1])[::-1], a)
+    assert not a[7].any() and 0.05 < (a == 0).all(axis=1).mean() < 0.95
+    small = np.stack([dec.min_sum_batch(pmf[i : i + 1])[0] for i in (0, 63, 64, 500, 1023)])  # batch 1: the wave-per-check kernels
+    assert np.array_equal(small, a[[0, 63, 64, 500, 1023]])
+    dec.close()
+    gk = S.TannerGraph.from_coo(golden["generators"]["qary_qc_256_6_3_s0_cb2"])
+    deck = qary.decoder_class("DecoderN1280R512SW6")(gk.to_dense(np.int8), 3)
+    pb = rng.dirichlet(np.ones(5), size=(70, 768)).astype(np.float32)
+    ps = rng.dirichlet(np.ones(25), size=(70, 512)).astype(np.float32)
+    k = deck.min_sum_batch(pb, ps)
+    assert np.array_equal(deck.min_sum_batch(pb[::-1].copy(), ps[::-1].copy())[::-1], k)
+    assert np.array_equal(deck.min_sum_batch(pb[33:34], ps[33:34])[0], k[33])
+    deck.close()
