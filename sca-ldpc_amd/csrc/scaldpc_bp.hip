@@ -73,6 +73,7 @@ struct Knobs {
     int var_order = -1;       // k_var launch order: bit 0 = inside a degree by first edge id, bit 1 = heaviest columns first; -1 = auto
     int fuse_finalize = 1;    // tile early-exit loop: convergence test and latch in one launch (k_parity_fin); 0 = k_parity + k_finalize
     int speculate = 1;        // early-exit tile groups: stop at the hand-over point without polling once two groups in a row did (0 = always poll)
+    int first_fused = 1;      // iteration 1 of the tile kernels without its check pass (k_var<.., FIRST> from the first-message table); 0 = check pass + plain variable pass
     int test_overlap = 0;     // early-exit tile groups: 1 = the convergence test of iteration it runs on a side stream beside the check pass of it + 1 (A/B knob: measured 3.4 % SLOWER on the config-5 sweep, profiles/r03/ab_test_overlap.log)
     int var_form = 1;         // k_var: 0 = ids fetched edge by edge, 1 = all ids up front as wide scalar loads (default)
 };
@@ -163,6 +164,13 @@ struct scaldpc_bp {
     // that lives for one single decode (hqc.py:694) never pays for the tile kernels' tables, a
     // benchmark never for the row-parallel ones.  What the builders need stays on the host:
     int *d_tile_tab = nullptr;  // row descriptors, k_var records, re-laid edge list (d_row_list, d_var_meta, d_csc_list)
+    // iteration 1 without its check pass: {first check-to-variable message of a zero-syndrome codeword, row} per position
+    // of the re-laid edge list; valid for one (method, alpha of iteration 1) and the current priors / graph
+    int2 *d_first_tab = nullptr;
+    size_t cap_first = 0;
+    bool first_valid = false;
+    int first_method = -1;
+    float first_alpha = 0.0f;
     int *d_el_tab = nullptr;    // k_el_var slots and wave info (d_el_slots, d_el_winfo)
     std::vector<int> hg_row_ptr, hg_cdeg, hg_col_ptr, hg_csc_edge;
     HostBuckets hg_var, hg_row;
@@ -213,6 +221,7 @@ bool set_knob(Knobs &k, const char *key, const char *val)
     else if (!strcmp(key, "speculate")) k.speculate = (int)x != 0;
     else if (!strcmp(key, "fuse_finalize")) k.fuse_finalize = (int)x != 0;
     else if (!strcmp(key, "test_overlap")) k.test_overlap = (int)x != 0;
+    else if (!strcmp(key, "first_fused")) k.first_fused = (int)x != 0;
     else return false;
     return true;
 }
@@ -222,7 +231,7 @@ void knobs_from_env(Knobs &k)
     static const char *const names[][2] = {{"SCALDPC_PATH", "path"}, {"SCALDPC_SPLIT", "split"},
                                            {"SCALDPC_GROUP_MB", "group_mb"}, {"SCALDPC_EL_MAX", "el_max"},
                                            {"SCALDPC_EL_FUSE", "el_fuse"}, {"SCALDPC_COMPACT_AFTER", "compact_after"},
-                                           {"SCALDPC_VAR_ORDER", "var_order"}, {"SCALDPC_VAR_FORM", "var_form"}, {"SCALDPC_SPECULATE", "speculate"}, {"SCALDPC_FUSE_FINALIZE", "fuse_finalize"}, {"SCALDPC_TEST_OVERLAP", "test_overlap"}};
+                                           {"SCALDPC_VAR_ORDER", "var_order"}, {"SCALDPC_VAR_FORM", "var_form"}, {"SCALDPC_SPECULATE", "speculate"}, {"SCALDPC_FUSE_FINALIZE", "fuse_finalize"}, {"SCALDPC_TEST_OVERLAP", "test_overlap"}, {"SCALDPC_FIRST_FUSED", "first_fused"}};
     for (auto &nm : names)
         if (const char *e = getenv(nm[0])) (void)set_knob(k, nm[1], e);
     if (getenv("SCALDPC_MINSUM_LOOP")) k.minsum_loop = 1;  // presence switches it on, as before
@@ -442,6 +451,7 @@ int ensure_tile_tables(scaldpc_bp *h)
             std::swap_ranges(meta + i * VAR_REC, meta + (i + 1) * VAR_REC, meta + j * VAR_REC);
     }
     SC_TRY(upload_table(&h->d_tile_tab, host, total));
+    h->first_valid = false;  // (first_tab follows the re-laid edge list)
     h->d_var_meta = h->d_tile_tab + o_var_meta;
     h->d_csc_list = h->d_tile_tab + o_csc_list;
     h->d_row_list = h->d_tile_tab + o_row_list;
@@ -637,12 +647,81 @@ int launch_check(scaldpc_bp *h, int method, float alpha, int G, const u64 *synd_
     return 0;
 }
 
+// Can iteration 1 run without its check pass (k_var<.., FIRST>)?  The first messages come from the row-parallel check
+// kernel (rows of at most 64 edges), the first variable pass keeps every column in registers (columns of at most 64).
+bool first_fusable(const scaldpc_bp *h, int method)
+{
+    return h->kn.first_fused && h->kn.var_form == 1 && fused_init(h, method) && h->E > 0 && h->max_row_deg <= 64 &&
+           h->max_col_deg <= 64 && !h->hg_var.has_generic;
+}
+
+// first_tab for (method, alpha of iteration 1) and the current priors: the row-parallel check kernel decodes the first
+// pass of ONE codeword with an all-zero syndrome into a scratch array (its values are the tile kernels' own, bit for
+// bit), k_first_tab lays them out beside each edge's row in the order of the re-laid edge list.
+int ensure_first_table(scaldpc_bp *h, int method, float alpha1, hipStream_t s)
+{
+    if (h->first_valid && h->first_method == method && h->first_alpha == alpha1) return 0;
+    const size_t need = (size_t)h->E + 128;  // (a column's scalar loads may run past its last edge, as in the edge list)
+    if (need > h->cap_first) {
+        dev_free(h->d_first_tab);
+        h->cap_first = 0;
+        SC_TRY(dev_alloc(&h->d_first_tab, need + need / 8));
+        h->cap_first = need + need / 8;
+    }
+    float *tmp = nullptr;
+    u64 *zero = nullptr;
+    SC_TRY(dev_alloc(&tmp, (size_t)h->E));
+    int rc = dev_alloc(&zero, (size_t)h->m + 1);
+    if (rc) {
+        dev_free(tmp);
+        return rc;
+    }
+    hipError_t e = hipMemsetAsync(zero, 0, sizeof(u64) * ((size_t)h->m + 1), s);
+    if (e == hipSuccess) e = hipMemsetAsync(h->d_first_tab, 0, sizeof(int2) * h->cap_first, s);
+    if (e == hipSuccess) {
+        dim3 grid((h->m + 3) / 4, 1);
+        if (method == SCALDPC_BP_MIN_SUM)
+            hipLaunchKernelGGL((k_el_check<SCALDPC_BP_MIN_SUM, true>), grid, dim3(256), 0, s, h->d_row_ptr, h->d_col_idx, h->d_prior,
+                               tmp, zero, zero + h->m, 0, h->m, h->E, alpha1, (const u64 *)nullptr, (int *)nullptr);
+        else
+            hipLaunchKernelGGL((k_el_check<SCALDPC_BP_PRODUCT_SUM, true>), grid, dim3(256), 0, s, h->d_row_ptr, h->d_col_idx,
+                               h->d_prior, tmp, zero, zero + h->m, 0, h->m, h->E, alpha1, (const u64 *)nullptr, (int *)nullptr);
+        hipLaunchKernelGGL(k_first_tab, dim3((unsigned)((h->E + 255) / 256)), dim3(256), 0, s, h->d_csc_list, tmp, h->d_row_ptr, h->m,
+                           h->E, h->d_first_tab);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(s);  // tmp / zero go back to the allocator below
+    dev_free(tmp);
+    dev_free(zero);
+    if (e != hipSuccess) return fail(SCALDPC_EHIP, "first-message table: %s", hipGetErrorString(e));
+    h->first_valid = true;
+    h->first_method = method;
+    h->first_alpha = alpha1;
+    return 0;
+}
+
+// first_synd: non-null = iteration 1 without its check pass (the group's syndrome planes; ensure_first_table first)
 int launch_var(scaldpc_bp *h, int G, float *post_g, u64 *hard_g, const u64 *done_g, int skip_done, int write_out,
-               hipStream_t s, int tile0 = 0)
+               hipStream_t s, int tile0 = 0, const u64 *first_synd = nullptr)
 {
     dim3 grid(h->var_bk.blk[h->var_bk.nb], G);
     float *const msg0 = h->d_msg + (size_t)tile0 * h->E * TW;
     float *const scr0 = h->d_scratch ? h->d_scratch + (size_t)tile0 * h->E * TW : nullptr;
+    if (first_synd) {
+#define VAR_FIRST(CAP)                                                                                              \
+    hipLaunchKernelGGL((k_var<CAP, 1, true>), grid, dim3(256), 0, s, h->var_bk, h->d_var_meta, h->d_col_ptr, h->d_csc_list, \
+                       h->d_prior, msg0, scr0, post_g, hard_g, done_g, skip_done, h->n, h->E, write_out,            \
+                       (const int2 *)h->d_first_tab, first_synd, h->m)
+        if (h->max_col_deg <= 16)
+            VAR_FIRST(16);
+        else if (h->max_col_deg <= 32)
+            VAR_FIRST(32);
+        else
+            VAR_FIRST(64);
+#undef VAR_FIRST
+        LAUNCH_CHECK();
+        return 0;
+    }
 #define VAR_LAUNCH(CAP, FORM)                                                                                       \
     hipLaunchKernelGGL((k_var<CAP, FORM>), grid, dim3(256), 0, s, h->var_bk, h->d_var_meta, h->d_col_ptr, h->d_csc_list, \
                        h->d_prior, msg0, scr0, post_g, hard_g, done_g, skip_done, h->n, h->E, write_out)
@@ -881,10 +960,14 @@ int iterate_tiles(scaldpc_bp *h, const TileState &st, int g0, int g, int max_ite
         }
         return 0;
     };
+    // iteration 1 without its check pass: the first variable pass reads the first-message table and the syndrome planes
+    const bool first_fuse = first_fusable(h, method);
+    if (first_fuse) SC_TRY(ensure_first_table(h, method, alpha_for(alpha, 1), s));
     bool set_phase = true;  // (re-)establish the one-kernel offset between neighbouring lanes
     for (int it = 1; it <= max_iter; it++) {
         const bool last = it == max_iter;
-        for (int k = 0; k < nl; k++) {
+        const bool no_check = first_fuse && it == 1;
+        for (int k = 0; k < nl && !no_check; k++) {
             const int ta = g0 + t0[k];
             SC_TRY(launch_check(h, method, alpha_for(alpha, it), gs[k], st.synd + (size_t)ta * h->m, st.done + ta, skip, lane[k],
                                 fused && it == 1, t0[k]));
@@ -893,12 +976,13 @@ int iterate_tiles(scaldpc_bp *h, const TileState &st, int g0, int g, int max_ite
                 SC_HIP(hipStreamWaitEvent(lane[k + 1], h->ev_phase[k + 1], 0));
             }
         }
-        set_phase = false;
+        if (!no_check) set_phase = false;  // (a first iteration without check passes leaves the offset to the second)
         for (int k = 0; k < nl; k++) {
             const int ta = g0 + t0[k];
             SC_TRY(wait_test(k));  // the test of the previous iteration decides which codewords this pass may still write
             SC_TRY(launch_var(h, gs[k], st.post ? st.post + (size_t)ta * h->n * TW : nullptr, st.hard + (size_t)ta * h->n,
-                              st.done + ta, skip, (early || last) ? 1 : 0, lane[k], t0[k]));
+                              st.done + ta, skip, (early || last) ? 1 : 0, lane[k], t0[k],
+                              no_check ? st.synd + (size_t)ta * h->m : nullptr));
             if ((early || last) && h->kn.fuse_finalize) {  // convergence test + latch, one launch
                 hipStream_t ts = lane[k];
                 if (ovl) {
@@ -1386,6 +1470,7 @@ int scaldpc_bp_set_channel_probs(scaldpc_bp *h, const double *probs)
     SC_HIP(hipMemcpy(h->d_prior, llr.data(), sizeof(float) * h->n, hipMemcpyHostToDevice));
     h->h_probs.assign(probs, probs + h->n);
     h->thr_valid = false;
+    h->first_valid = false;
     h->have_prior = true;
     h->prior_n = h->n;
     return 0;
@@ -1418,6 +1503,7 @@ int scaldpc_bp_set_channel_probs_tail(scaldpc_bp *h, int32_t first, int32_t coun
     h->h_probs.resize(h->n, 0.0);
     std::copy(probs, probs + count, h->h_probs.begin() + first);
     h->thr_valid = false;
+    h->first_valid = false;
     h->prior_n = std::max(h->prior_n, first + count);
     h->have_prior = true;
     return 0;
@@ -1587,6 +1673,7 @@ int scaldpc_bp_append_rows(scaldpc_bp *h, int32_t nrows, const int32_t *row_ptr,
     h->full_stale = true;  // CSC, degree buckets, identity block, tile tables: rebuilt when the tile / LDS kernels are next needed
     h->h_probs.resize(new_n, 0.0);
     h->thr_valid = false;
+    h->first_valid = false;
     dev_free(h->d_thr);
     dev_free(h->d_msg);
     dev_free(h->d_scratch);
@@ -2145,6 +2232,7 @@ void scaldpc_bp_destroy(scaldpc_bp *h)
     dev_free(h->d_csr_rp); dev_free(h->d_csr_ci); dev_free(h->d_prior_buf); dev_free(h->d_pairs);
     cached_free(h->h_pairs);
     dev_free(h->d_tile_tab);
+    dev_free(h->d_first_tab);
     dev_free(h->d_el_tab);
     dev_free(h->d_msg); dev_free(h->d_scratch); dev_free(h->d_post);
     dev_free(h->d_synd); dev_free(h->d_recv); dev_free(h->d_hard); dev_free(h->d_done);

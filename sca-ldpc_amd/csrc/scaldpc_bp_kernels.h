@@ -863,6 +863,69 @@ __device__ __forceinline__ float var_col_s(float *tile_base, unsigned lane, cons
     return temp;
 }
 
+// ITERATION 1 without its check pass.  The first check-to-variable message of an edge depends on the codeword only
+// through the SYNDROME BIT of the edge's row: its magnitude is a function of the row's priors, its sign the parity of
+// the priors' signs XOR that bit.  So the host keeps, per edge, the message of a codeword with an all-zero syndrome
+// (`first_tab`: computed once per prior set by the row-parallel check kernel, whose values are the tile kernels' own,
+// bit for bit) next to the edge's row, and the first variable pass takes c2v = first ^ (syndrome bit << 31) from scalar
+// loads instead of gathering 256-B message rows a check pass would have had to write first: one launch and
+// 8 E bytes per codeword less, same sums in the same order, identical results.
+//   ft: the column's slice of first_tab (laid out like the re-laid edge list), {message bits, row}
+template <int MAXD>
+__device__ __forceinline__ float var_col_first(float *tile_base, unsigned lane, const int4 *__restrict__ rec4,
+                                               const int *__restrict__ ce1, const int2 *__restrict__ ft,
+                                               const u64 *__restrict__ synd_t, int d, float pr)
+{
+    int eid[MAXD];
+    {
+        const int4 a = rec4[1], b = rec4[2], c = rec4[3], e = rec4[4];
+        const int in16[16] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, c.x, c.y, c.z, c.w, e.x, e.y, e.z, e.w};
+#pragma unroll
+        for (int k = 0; k < MAXD && k < VAR_INLINE; k++) eid[k] = in16[k];
+#pragma unroll
+        for (int k = VAR_INLINE; k < MAXD; k++) eid[k] = ce1[k];
+    }
+    float mm[MAXD], pp[MAXD];
+#pragma unroll
+    for (int k = 0; k < MAXD; k++)
+        if (k < d) {
+            const int2 f = ft[k];  // uniform address: scalar load
+            const u64 w = synd_t[rfl(f.y)];
+            mm[k] = __uint_as_float((unsigned)rfl(f.x) ^ (((unsigned)(w >> lane) & 1u) << 31));
+        }
+    float temp = pr;
+#pragma unroll
+    for (int k = 0; k < MAXD; k++)
+        if (k < d) {
+            pp[k] = temp;
+            temp += mm[k];
+        }
+    float suf = 0.0f;
+#pragma unroll
+    for (int k = MAXD - 1; k >= 0; k--)
+        if (k < d) {
+            (tile_base + (size_t)rfl(eid[k]) * TW)[lane] = pp[k] + suf;
+            suf += mm[k];
+        }
+    return temp;
+}
+
+// first_tab[pos] = {first message of edge list[pos] (zero-syndrome codeword), its row}: one thread per list position.
+// The row of an edge = the last r with row_ptr[r] <= e (binary search).  grid ceil(E/256).
+__global__ __launch_bounds__(256) void k_first_tab(const int *__restrict__ list, const float *__restrict__ first_msg,
+                                                   const int *__restrict__ row_ptr, int m, long E, int2 *__restrict__ tab)
+{
+    const long p = (long)blockIdx.x * 256 + threadIdx.x;
+    if (p >= E) return;
+    const int e = list[p];
+    int lo = 0, hi = m - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (row_ptr[mid] <= e) lo = mid; else hi = mid - 1;
+    }
+    tab[p] = make_int2(__float_as_int(first_msg[e]), lo);
+}
+
 // Any-degree fallback: prefix parked in the scratch array, second sweep re-reads c2v
 // just before overwriting it.
 __device__ __forceinline__ float var_col_generic(float *mt, float *st, const int *__restrict__ ce, int d, float pr)
@@ -888,13 +951,16 @@ __device__ __forceinline__ float var_col_generic(float *mt, float *st, const int
 // write_out: also emit hard-decision planes (merged under the done mask) and, if
 // `post` is non-null, the posterior of every not-yet-frozen codeword.
 // CAP = largest unroll bound compiled in (see k_check_tanh).
-template <int CAP, int FORM = 0>
+// FIRST (with FORM 1 only): iteration 1 straight from first_tab and the syndrome planes (var_col_first); every column
+// of the graph has a register-resident degree then (the host checks: max column degree <= 64).
+template <int CAP, int FORM = 0, bool FIRST = false>
 __global__ __launch_bounds__(256) void k_var(Buckets bk, const int *__restrict__ list,
                                              const int *__restrict__ col_ptr, const int *__restrict__ csc_edge,
                                              const float *__restrict__ prior, float *msg, float *scratch,
                                              float *__restrict__ post, u64 *__restrict__ hard,
                                              const u64 *__restrict__ done, int skip_done, int n, long E,
-                                             int write_out)
+                                             int write_out, const int2 *__restrict__ first_tab = nullptr,
+                                             const u64 *__restrict__ synd = nullptr, int m = 0)
 {
     const int lane = threadIdx.x & 63;
     const int tl = blockIdx.y;
@@ -913,7 +979,27 @@ __global__ __launch_bounds__(256) void k_var(Buckets bk, const int *__restrict__
     const int *ce = csc_edge + cb, *ce0 = rec + 4;
     const float pr = prior[v];
     float L = pr;
-    if constexpr (FORM == 1) {
+    if constexpr (FORM == 1 && FIRST) {
+        float *tb = msg + (size_t)tl * E * TW;
+        const unsigned ul = threadIdx.x & 63u;
+        const int4 *r4 = (const int4 *)rec;
+        const int2 *ft = first_tab + cb;
+        const u64 *st = synd + (size_t)tl * m;
+        switch (rec[3]) {
+            case 1: L = var_col_first<1>(tb, ul, r4, ce, ft, st, d, pr); break;
+            case 2: L = var_col_first<2>(tb, ul, r4, ce, ft, st, d, pr); break;
+            case 4: L = var_col_first<4>(tb, ul, r4, ce, ft, st, d, pr); break;
+            case 8: L = var_col_first<8>(tb, ul, r4, ce, ft, st, d, pr); break;
+            case 16: L = var_col_first<16>(tb, ul, r4, ce, ft, st, d, pr); break;
+            case 32:
+                if constexpr (CAP >= 32) L = var_col_first<32>(tb, ul, r4, ce, ft, st, d, pr);
+                break;
+            case 64:
+                if constexpr (CAP >= 64) L = var_col_first<64>(tb, ul, r4, ce, ft, st, d, pr);
+                break;
+            default: break;  // (no any-degree columns when this instantiation is launched)
+        }
+    } else if constexpr (FORM == 1) {
         float *tb = msg + (size_t)tl * E * TW;
         const unsigned ul = threadIdx.x & 63u;  // unsigned lane index: lets the gathers take the SGPR-base form
         const int4 *r4 = (const int4 *)rec;

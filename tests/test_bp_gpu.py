@@ -322,6 +322,39 @@ def test_hqc256_bench_configuration(oracle, decode_path):
 
 
 @pytest.mark.parametrize("method", ["min_sum", "product_sum"])
+def test_first_iteration_without_its_check_pass_is_invisible(oracle, method):
+    """Iteration 1 of the tile kernels runs without a check pass: the first check-to-variable message of an edge is the
+    message of a zero-syndrome codeword with the sign flipped by the row's syndrome bit, so the first variable pass reads
+    a per-edge table instead of message rows (`first_fused`, default on).  Same results as with the check pass, bit for
+    bit -- decisions, posteriors, iteration counts, flags -- for both rules, with and without early exit, ragged batches,
+    +-inf priors, the alpha = 1 - 2^-it schedule, priors changed on a live decoder, and rows appended to it."""
+    for eps, alpha in ((0.03, 1.0), (0.0, 0.0), (0.03, 0.6)):
+        if method == "product_sum" and alpha != 1.0:
+            continue
+        H, Hin, probs, msg, y = hqc_instance(1201, 9, 420, 6, eps, 333, seed=61, flip=eps > 0)
+        outs = {}
+        for ff in (1, 0):
+            with np.errstate(divide="ignore"):
+                dec = bp.bp_decoder(H, max_iter=30, bp_method=method, channel_probs=probs, ms_scaling_factor=alpha)
+            dec.configure(path="stream", first_fused=ff)
+            dec.set_tile_group(2)
+            res = [dec.decode_batch(msg, early_exit=True, want_llr=True), dec.decode_batch(msg[:70], early_exit=False, want_llr=True),
+                   dec.decode_batch(H.syndrome(msg[:130]), max_iter=1, early_exit=False, want_llr=True, input_vector_type="syndrome")]
+            p2 = probs.copy()
+            p2[:1201] = 0.011  # new priors on the live decoder: the table must follow
+            dec.update_channel_probs(p2)
+            res.append(dec.decode_batch(msg[:100], early_exit=True, want_llr=True))
+            outs[ff] = res
+            dec.close()
+        for a, b in zip(outs[1], outs[0]):
+            for k in ("bits", "llr", "iters", "converged"):
+                assert np.array_equal(a[k], b[k], equal_nan=(k == "llr")), (eps, alpha, k)
+        with np.errstate(divide="ignore"):
+            ref = oracle.bp_decode_batch(H, probs, msg, 1, 30, ORACLE_METHOD[method], alpha=alpha, dtype="f32", threads=8)
+        compare(outs[1][0], ref, method)
+
+
+@pytest.mark.parametrize("method", ["min_sum", "product_sum"])
 def test_full_size_invariances(method, decode_path):
     """Size-independent properties at BASELINE config 2's full size (HQC-128 graph, batch 4096, no oracle needed):
       * a codeword's result does not depend on WHERE in the batch it sits (tile, lane, stream lane, tile group):
