@@ -355,7 +355,7 @@ def test_full_size_invariances(golden):
     rng = np.random.RandomState(404)
     p = 1 / 3
     good, bad = np.array([p, 1.75 * p, 0.25 * p]), np.array([p, 0.25 * p, 1.75 * p])
-    pmf = np.where((rng.rand(1024, 450) < 0.02)[:, :, None], bad, good).astype(np.float32)
+    pmf = np.where((rng.rand(1024, 450) < 0.005)[:, :, None], bad, good).astype(np.float32)  # (bench.py's config-4 inputs: all_zero_rate 0.23)
     pmf[7] = good
     a = dec.min_sum_batch(pmf)
     assert np.array_equal(dec.min_sum_batch(pmf[::-1])[::-1], a)
