@@ -886,12 +886,21 @@ __device__ __forceinline__ float var_col_first(float *tile_base, unsigned lane, 
         for (int k = VAR_INLINE; k < MAXD; k++) eid[k] = ce1[k];
     }
     float mm[MAXD], pp[MAXD];
+    // Lane j fetches the table entry of the column's j-th edge and then that edge's syndrome word: TWO vector round
+    // trips for the whole column, whatever its degree; edge k's pair then reaches every lane through v_readlane.
+    // (Through scalar loads the compiler makes every edge its own dependent `s_load; s_waitcnt; s_load; s_waitcnt`
+    // chain -- 22 round trips in a row for a degree-11 column -- or, with the loads hoisted out of the `k < d`
+    // predicate, still one `s_load; s_waitcnt` per syndrome word for want of SGPRs.)
+    int2 f = make_int2(0, 0);
+    if ((int)lane < d) f = ft[lane];
+    const u64 wv = synd_t[f.y];  // (lanes >= d read row 0: valid, unused)
+    const int wlo = (int)(unsigned)wv, whi = (int)(unsigned)(wv >> 32);
 #pragma unroll
     for (int k = 0; k < MAXD; k++)
         if (k < d) {
-            const int2 f = ft[k];  // uniform address: scalar load
-            const u64 w = synd_t[rfl(f.y)];
-            mm[k] = __uint_as_float((unsigned)rfl(f.x) ^ (((unsigned)(w >> lane) & 1u) << 31));
+            const unsigned lo = (unsigned)__builtin_amdgcn_readlane(wlo, k), hi = (unsigned)__builtin_amdgcn_readlane(whi, k);
+            const u64 w = ((u64)hi << 32) | lo;
+            mm[k] = __uint_as_float((unsigned)__builtin_amdgcn_readlane(f.x, k) ^ (((unsigned)(w >> lane) & 1u) << 31));
         }
     float temp = pr;
 #pragma unroll
