@@ -73,6 +73,7 @@ struct Knobs {
     int var_order = -1;       // k_var launch order: bit 0 = inside a degree by first edge id, bit 1 = heaviest columns first; -1 = auto
     int fuse_finalize = 1;    // tile early-exit loop: convergence test and latch in one launch (k_parity_fin); 0 = k_parity + k_finalize
     int speculate = 1;        // early-exit tile groups: stop at the hand-over point without polling once two groups in a row did (0 = always poll)
+    int fuse_test = 1;        // early-exit tile loop: the convergence test of iteration it rides on the check pass of it + 1 wherever the host does not need the verdict in between
     int first_fused = 1;      // iteration 1 of the tile kernels without its check pass (k_var<.., FIRST> from the first-message table); 0 = check pass + plain variable pass
     int test_overlap = 0;     // early-exit tile groups: 1 = the convergence test of iteration it runs on a side stream beside the check pass of it + 1 (A/B knob: measured 3.4 % SLOWER on the config-5 sweep, profiles/r03/ab_test_overlap.log)
     int var_form = 1;         // k_var: 0 = ids fetched edge by edge, 1 = all ids up front as wide scalar loads (default)
@@ -222,6 +223,7 @@ bool set_knob(Knobs &k, const char *key, const char *val)
     else if (!strcmp(key, "fuse_finalize")) k.fuse_finalize = (int)x != 0;
     else if (!strcmp(key, "test_overlap")) k.test_overlap = (int)x != 0;
     else if (!strcmp(key, "first_fused")) k.first_fused = (int)x != 0;
+    else if (!strcmp(key, "fuse_test")) k.fuse_test = (int)x != 0;
     else return false;
     return true;
 }
@@ -231,7 +233,7 @@ void knobs_from_env(Knobs &k)
     static const char *const names[][2] = {{"SCALDPC_PATH", "path"}, {"SCALDPC_SPLIT", "split"},
                                            {"SCALDPC_GROUP_MB", "group_mb"}, {"SCALDPC_EL_MAX", "el_max"},
                                            {"SCALDPC_EL_FUSE", "el_fuse"}, {"SCALDPC_COMPACT_AFTER", "compact_after"},
-                                           {"SCALDPC_VAR_ORDER", "var_order"}, {"SCALDPC_VAR_FORM", "var_form"}, {"SCALDPC_SPECULATE", "speculate"}, {"SCALDPC_FUSE_FINALIZE", "fuse_finalize"}, {"SCALDPC_TEST_OVERLAP", "test_overlap"}, {"SCALDPC_FIRST_FUSED", "first_fused"}};
+                                           {"SCALDPC_VAR_ORDER", "var_order"}, {"SCALDPC_VAR_FORM", "var_form"}, {"SCALDPC_SPECULATE", "speculate"}, {"SCALDPC_FUSE_FINALIZE", "fuse_finalize"}, {"SCALDPC_TEST_OVERLAP", "test_overlap"}, {"SCALDPC_FIRST_FUSED", "first_fused"}, {"SCALDPC_FUSE_TEST", "fuse_test"}};
     for (auto &nm : names)
         if (const char *e = getenv(nm[0])) (void)set_knob(k, nm[1], e);
     if (getenv("SCALDPC_MINSUM_LOOP")) k.minsum_loop = 1;  // presence switches it on, as before
@@ -598,8 +600,18 @@ bool fused_init(const scaldpc_bp *h, int method)
     return h->E > 0 && (method == SCALDPC_BP_MIN_SUM || h->max_row_deg <= ROW_CAP);
 }
 
+// Which check kernels can carry the convergence test of the previous iteration (fused_test)?  The register-resident
+// ones: the tanh kernel always, min-sum in its exact-degree form.
+bool check_can_test(const scaldpc_bp *h, int method)
+{
+    if (h->E == 0) return false;
+    if (method == SCALDPC_BP_MIN_SUM) return h->max_row_deg <= ROW_CAP && h->kn.minsum_loop == 0;
+    return true;
+}
+
+// ft: non-null = this pass also runs the convergence test of the previous iteration (check_can_test(h, method), never `first`)
 int launch_check(scaldpc_bp *h, int method, float alpha, int G, const u64 *synd_g, const u64 *done_g, int skip_done,
-                 hipStream_t s, bool first = false, int tile0 = 0)
+                 hipStream_t s, bool first = false, int tile0 = 0, const FusedTest *ft = nullptr)
 {
     if (h->E == 0) return 0;
     float *const msg0 = h->d_msg + (size_t)tile0 * h->E * TW;  // tile0: first tile of a sub-group inside the group's array
@@ -615,13 +627,19 @@ int launch_check(scaldpc_bp *h, int method, float alpha, int G, const u64 *synd_
 #define MSX_LAUNCH(CAP, F)                                                                                          \
     hipLaunchKernelGGL((k_check_minsum_x<CAP, F>), gridx, dim3(256), 0, s, h->d_row_list, msg0, synd_g, done_g, skip_done, \
                        h->m, h->E, alpha, h->d_col_idx, h->d_prior)
-            if (h->max_row_deg <= 16) {
+#define MSX_PAR(CAP)                                                                                                \
+    hipLaunchKernelGGL((k_check_minsum_x<CAP, false, true>), gridx, dim3(256), 0, s, h->d_row_list, msg0, synd_g, done_g,  \
+                       skip_done, h->m, h->E, alpha, h->d_col_idx, h->d_prior, *ft)
+            if (ft && !first) {
+                if (h->max_row_deg <= 16) MSX_PAR(16); else if (h->max_row_deg <= 32) MSX_PAR(32); else MSX_PAR(64);
+            } else if (h->max_row_deg <= 16) {
                 if (first) MSX_LAUNCH(16, true); else MSX_LAUNCH(16, false);
             } else if (h->max_row_deg <= 32) {
                 if (first) MSX_LAUNCH(32, true); else MSX_LAUNCH(32, false);
             } else {
                 if (first) MSX_LAUNCH(64, true); else MSX_LAUNCH(64, false);
             }
+#undef MSX_PAR
 #undef MSX_LAUNCH
         } else if (h->max_row_deg <= ROW_CAP) {
             if (first) MS_LAUNCH(false, true); else MS_LAUNCH(false, false);
@@ -634,13 +652,19 @@ int launch_check(scaldpc_bp *h, int method, float alpha, int G, const u64 *synd_
 #define TANH_LAUNCH(CAP, F)                                                                                         \
     hipLaunchKernelGGL((k_check_tanh<CAP, F>), grid, dim3(256), 0, s, h->row_bk, h->d_row_list, h->d_row_ptr, msg0, \
                        scr0, synd_g, done_g, skip_done, h->m, h->E, h->d_col_idx, h->d_prior)
-        if (h->max_row_deg <= 16) {
+#define TANH_PAR(CAP)                                                                                               \
+    hipLaunchKernelGGL((k_check_tanh<CAP, false, true>), grid, dim3(256), 0, s, h->row_bk, h->d_row_list, h->d_row_ptr, msg0, \
+                       scr0, synd_g, done_g, skip_done, h->m, h->E, h->d_col_idx, h->d_prior, *ft)
+        if (ft && !first) {
+            if (h->max_row_deg <= 16) TANH_PAR(16); else if (h->max_row_deg <= 32) TANH_PAR(32); else TANH_PAR(64);
+        } else if (h->max_row_deg <= 16) {
             if (first) TANH_LAUNCH(16, true); else TANH_LAUNCH(16, false);
         } else if (h->max_row_deg <= 32) {
             if (first) TANH_LAUNCH(32, true); else TANH_LAUNCH(32, false);
         } else {
             if (first) TANH_LAUNCH(64, true); else TANH_LAUNCH(64, false);
         }
+#undef TANH_PAR
 #undef TANH_LAUNCH
     }
     LAUNCH_CHECK();
@@ -963,14 +987,26 @@ int iterate_tiles(scaldpc_bp *h, const TileState &st, int g0, int g, int max_ite
     // iteration 1 without its check pass: the first variable pass reads the first-message table and the syndrome planes
     const bool first_fuse = first_fusable(h, method);
     if (first_fuse) SC_TRY(ensure_first_table(h, method, alpha_for(alpha, 1), s));
+    // The convergence test of iteration it rides on the check pass of it + 1 (fused_test) wherever the host does not need
+    // its verdict in between: at the iterations it polls at, stops a group at, or ends with, the stand-alone launch stays.
+    const bool ride = early && h->kn.fuse_finalize && h->kn.fuse_test && !ovl && check_can_test(h, method);
+    bool verdict_pending[MAX_LANES] = {};  // lane k's last variable pass has not been tested yet: its next check pass will
     bool set_phase = true;  // (re-)establish the one-kernel offset between neighbouring lanes
     for (int it = 1; it <= max_iter; it++) {
         const bool last = it == max_iter;
         const bool no_check = first_fuse && it == 1;
+        // (decided before anything of this iteration is enqueued: the host's own sync points)
+        const bool poll = (it % poll_every == 0 || it == 1 || it == defer_after) && (!poll_hint || it >= *poll_hint);
         for (int k = 0; k < nl && !no_check; k++) {
             const int ta = g0 + t0[k];
+            FusedTest ft{};
+            if (verdict_pending[k]) {
+                ft = FusedTest{st.hard + (size_t)ta * h->n, st.unsat + (size_t)ta * pw, st.done + ta, st.conv + ta,
+                               st.iters + (size_t)ta * TW, h->d_remaining + (it - 1), h->n, pw, it - 1};
+                verdict_pending[k] = false;
+            }
             SC_TRY(launch_check(h, method, alpha_for(alpha, it), gs[k], st.synd + (size_t)ta * h->m, st.done + ta, skip, lane[k],
-                                fused && it == 1, t0[k]));
+                                fused && it == 1, t0[k], ft.hard ? &ft : nullptr));
             if (set_phase && k + 1 < nl) {
                 SC_HIP(hipEventRecord(h->ev_phase[k + 1], lane[k]));
                 SC_HIP(hipStreamWaitEvent(lane[k + 1], h->ev_phase[k + 1], 0));
@@ -983,7 +1019,9 @@ int iterate_tiles(scaldpc_bp *h, const TileState &st, int g0, int g, int max_ite
             SC_TRY(launch_var(h, gs[k], st.post ? st.post + (size_t)ta * h->n * TW : nullptr, st.hard + (size_t)ta * h->n,
                               st.done + ta, skip, (early || last) ? 1 : 0, lane[k], t0[k],
                               no_check ? st.synd + (size_t)ta * h->m : nullptr));
-            if ((early || last) && h->kn.fuse_finalize) {  // convergence test + latch, one launch
+            if (ride && !last && !poll) {
+                verdict_pending[k] = true;  // the next check pass of this lane carries the test
+            } else if ((early || last) && h->kn.fuse_finalize) {  // convergence test + latch, one launch
                 hipStream_t ts = lane[k];
                 if (ovl) {
                     ts = h->test_stream[k];
@@ -1011,8 +1049,7 @@ int iterate_tiles(scaldpc_bp *h, const TileState &st, int g0, int g, int max_ite
             }
         }
         // a poll drains the queue (the GPU idles while the host turns around): skip the poll
-        // points at which the call's earlier groups saw no codeword finish yet
-        const bool poll = (it % poll_every == 0 || it == 1 || it == defer_after) && (!poll_hint || it >= *poll_hint);
+        // points at which the call's earlier groups saw no codeword finish yet (`poll`, above)
         if (early && !last && poll && ps && it == defer_after && defer_after > 0 && 2 * it < max_iter && ps->streak >= 2 &&
             ps->since_poll < 15 && h->kn.speculate) {
             ps->since_poll++;  // stop here unseen, as the last groups did

@@ -352,6 +352,72 @@ __global__ __launch_bounds__(256) void k_parity_fin(const int *__restrict__ row_
     }
 }
 
+// The convergence test of iteration it - 1 RIDING ON the check pass of iteration it (early-exit tile loop).  The test
+// reads only the decisions the last variable pass wrote, the check pass only the messages: a check-pass wave has its
+// row in hand anyway, so it XORs the row's decision planes (lanes over the row's edges: one coalesced index load, one
+// gather, a butterfly), the block ORs its four rows' mismatches into the tile's accumulator and draws a ticket, the
+// block that draws the last ticket latches the tile -- k_parity_fin's protocol word for word, minus the launch and
+// minus its own pass over row_ptr.  The variable pass that follows is the first reader of the `done` mask that
+// matters, and it starts after this kernel.  Iterations at which the host polls (or stops a group) keep the
+// stand-alone k_parity_fin: there the verdict is needed before the next check pass would be launched.
+struct FusedTest {
+    const u64 *hard;  // [tile][n] decisions of iteration it_prev (the launch's first tile)
+    u64 *unsat;       // [tile][pw]: word 0 accumulator, word 1 block counter; zero on entry and exit
+    u64 *done, *conv; // [tile]
+    int *iters;       // [tile][64]
+    int *remaining;   // += codewords still running after the latch
+    int n, pw, it_prev;
+};
+
+// Called by EVERY thread of EVERY block of the tile's launch row (before any wave leaves): r < 0 = this wave has no row.
+__device__ __forceinline__ void fused_test(const FusedTest &ft, int tl, int r, int e0, int deg, const int *__restrict__ col_idx,
+                                           const u64 *__restrict__ synd, int m, u64 dw)
+{
+    __shared__ u64 sbad[4];
+    __shared__ int s_last;
+    const int lane = threadIdx.x & 63;
+    u64 bad = 0;
+    if (r >= 0) {
+        const u64 *bt = ft.hard + (size_t)tl * ft.n;
+        u64 x = 0;
+        for (int e = e0 + lane; e < e0 + deg; e += 64) x ^= bt[col_idx[e]];
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) x ^= __shfl_xor(x, off);
+        bad = x ^ synd[(size_t)tl * m + r];
+    }
+    if (lane == 0) sbad[threadIdx.x >> 6] = bad;
+    __syncthreads();
+    u64 *acc = ft.unsat + (size_t)tl * ft.pw;
+    if (threadIdx.x == 0) {
+        const u64 b = sbad[0] | sbad[1] | sbad[2] | sbad[3];
+        if (b) {
+            const u64 old = atomicOr(acc, b);
+            asm volatile("s_waitcnt vmcnt(0)" ::"v"((unsigned)old) : "memory");  // the OR is performed before the ticket is drawn
+        }
+        const unsigned tk = atomicAdd((unsigned *)(acc + 1), 1u);
+        s_last = tk == gridDim.x - 1;
+    }
+    __syncthreads();
+    if (!s_last || threadIdx.x >= 64) return;
+    const int c = threadIdx.x;
+    unsigned lo = 0, hi = 0;
+    if (c == 0) {
+        const u64 uw0 = atomicExch(acc, 0ull);
+        (void)atomicExch((unsigned *)(acc + 1), 0u);
+        lo = (unsigned)uw0;
+        hi = (unsigned)(uw0 >> 32);
+    }
+    const u64 uw = ((u64)(unsigned)rfl((int)hi) << 32) | (unsigned)rfl((int)lo);
+    const u64 newly = ~dw & ~uw;
+    if ((newly >> c) & 1) ft.iters[(long)tl * TW + c] = ft.it_prev;
+    if (c == 0) {
+        ft.done[tl] = dw | newly;
+        ft.conv[tl] |= newly;
+        const int rem = __popcll(~(dw | newly));
+        if (rem) atomicAdd(ft.remaining, rem);
+    }
+}
+
 // ---------------------------------------------------------------------------
 // K1  initial bit-to-check messages: msg[tile][e][:] = LLR prior of the edge's column.
 // grid (ceil(E/4), G), block 256 = 4 waves, wave = one 256 B edge row.
@@ -446,17 +512,26 @@ __device__ __forceinline__ void check_minsum_row(float *p, unsigned par, float a
         p[(size_t)k * TW] = ((k == ix) ? m2 : m1) * ((par ^ (unsigned)(x[k] <= 0.0f)) ? nalpha : alpha);
 }
 
-template <int CAP, bool FIRST>
+// PAR: the convergence test of the previous iteration rides on this pass (fused_test; early-exit runs, never FIRST).
+template <int CAP, bool FIRST, bool PAR = false>
 __global__ __launch_bounds__(256) void k_check_minsum_x(const int *__restrict__ list, float *msg,
-                                                        const u64 *__restrict__ synd, const u64 *__restrict__ done,
+                                                        const u64 *__restrict__ synd, const u64 *done,
                                                         int skip_done, int m, long E, float alpha,
-                                                        const int *__restrict__ col_idx, const float *__restrict__ prior)
+                                                        const int *__restrict__ col_idx, const float *__restrict__ prior,
+                                                        FusedTest ft = FusedTest{})
 {
     const int lane = threadIdx.x & 63;
     const int tl = blockIdx.y;
     const int *md = list + (size_t)rfl((int)blockIdx.x * 4 + (int)(threadIdx.x >> 6)) * 4;  // uniform address: scalar loads
-    if (skip_done && done[tl] == ~0ull) return;
+    u64 dw = 0;
+    if constexpr (PAR) {
+        dw = done[tl];
+        if (skip_done && dw == ~0ull) return;  // (uniform over the tile's blocks: no ticket is drawn for a frozen tile)
+    } else {
+        if (skip_done && done[tl] == ~0ull) return;
+    }
     const int r = md[0];
+    if constexpr (PAR) fused_test(ft, tl, r, md[1], md[2], col_idx, synd, m, dw);
     if (r < 0) return;
     const int e0 = md[1];
     const int deg = md[2];
@@ -577,20 +652,28 @@ __device__ __forceinline__ void check_tanh_row_generic(float *p, float *sc, int 
 // CAP = largest degree compiled in (the register budget follows the widest instantiation,
 // so graphs with narrow rows get the high-occupancy build).
 // grid (bk.blk[nb], G), block 256 = 4 rows of one bucket.
-template <int CAP, bool FIRST>
+// PAR: the convergence test of the previous iteration rides on this pass (fused_test; early-exit runs, never FIRST).
+template <int CAP, bool FIRST, bool PAR = false>
 __global__ __launch_bounds__(256) void k_check_tanh(Buckets bk, const int *__restrict__ list,
                                                     const int *__restrict__ row_ptr, float *msg, float *scratch,
-                                                    const u64 *__restrict__ synd, const u64 *__restrict__ done,
+                                                    const u64 *__restrict__ synd, const u64 *done,
                                                     int skip_done, int m, long E, const int *__restrict__ col_idx,
-                                                    const float *__restrict__ prior)
+                                                    const float *__restrict__ prior, FusedTest ft = FusedTest{})
 {
     const int lane = threadIdx.x & 63;
     const int tl = blockIdx.y;
     // one descriptor per WAVE of the launch: {row or -1 (padding), first edge, degree, 0 = any-degree
     // fallback}: a single load instead of bucket table -> row list -> row_ptr
     const int *md = list + (size_t)rfl((int)blockIdx.x * 4 + (int)(threadIdx.x >> 6)) * 4;  // uniform address: scalar loads
-    if (skip_done && done[tl] == ~0ull) return;
+    u64 dw = 0;
+    if constexpr (PAR) {
+        dw = done[tl];
+        if (skip_done && dw == ~0ull) return;  // (uniform over the tile's blocks: no ticket is drawn for a frozen tile)
+    } else {
+        if (skip_done && done[tl] == ~0ull) return;
+    }
     const int r = md[0];
+    if constexpr (PAR) fused_test(ft, tl, r, md[1], md[2], col_idx, synd, m, dw);
     if (r < 0) return;
     const int e0 = md[1];
     const int deg = md[2];

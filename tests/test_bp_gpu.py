@@ -357,6 +357,39 @@ def test_first_iteration_without_its_check_pass_is_invisible(oracle, method):
 
 
 @pytest.mark.parametrize("method", ["min_sum", "product_sum"])
+def test_convergence_test_riding_on_the_check_pass_is_invisible(oracle, method):
+    """Early-exit tile loop: the H e == s test of iteration it rides on the check pass of it + 1 (`fuse_test`, default
+    on) except where the host polls or stops.  Decisions, posteriors, ITERATION COUNTS and flags are those of the
+    stand-alone test launch, bit for bit: several tile groups with a ragged last one, one and two stream lanes,
+    compaction on and off, a graph with rows of mixed degree and an empty row, trials that converge at iteration 1."""
+    H, Hin, probs, msg, y = hqc_instance(997, 9, 450, 6, 0.03, 700, seed=21)
+    msg[:40, 997:] = H.syndrome(np.concatenate([y[:40], np.zeros((40, 450), np.uint8)], axis=1))  # noiseless checks: early convergers
+    rng = np.random.RandomState(8)
+    Hd = (rng.rand(60, 150) < 0.07).astype(np.int8)
+    Hd[5] = 0  # an empty row: its syndrome bit alone decides
+    G2 = S.TannerGraph.from_dense(Hd)
+    p2 = rng.uniform(0.01, 0.15, size=150)
+    s2 = G2.syndrome((rng.rand(200, 150) < p2[None, :]).astype(np.uint8))
+    for graph, pr, x, kind in ((H, probs, msg, "received_vector"), (G2, p2, s2, "syndrome")):
+        outs = {}
+        for ft in (1, 0):
+            res = []
+            for lanes, group, compact in ((2, 3, -1), (1, 2, 0), (2, 0, 2)):
+                dec = bp.bp_decoder(graph, max_iter=40, bp_method=method, channel_probs=pr)
+                dec.configure(path="stream", fuse_test=ft, split=lanes, compact_after=compact)
+                dec.set_tile_group(group)
+                res.append(dec.decode_batch(x, early_exit=True, want_llr=True, input_vector_type=kind))
+                dec.close()
+            outs[ft] = res
+        for a, b in zip(outs[1], outs[0]):
+            for k in ("bits", "llr", "iters", "converged"):
+                assert np.array_equal(a[k], b[k], equal_nan=(k == "llr")), k
+        ref = oracle.bp_decode_batch(graph, pr, x, 1 if kind == "received_vector" else 0, 40, ORACLE_METHOD[method], dtype="f32", threads=8)
+        compare(outs[1][0], ref, method)
+        assert len(np.unique(ref["iters"])) > 3  # a spread of iteration counts, so that latching at the right one matters
+
+
+@pytest.mark.parametrize("method", ["min_sum", "product_sum"])
 def test_full_size_invariances(method, decode_path):
     """Size-independent properties at BASELINE config 2's full size (HQC-128 graph, batch 4096, no oracle needed):
       * a codeword's result does not depend on WHERE in the batch it sits (tile, lane, stream lane, tile group):
