@@ -369,22 +369,27 @@ struct FusedTest {
     int n, pw, it_prev;
 };
 
-// Called by EVERY thread of EVERY block of the tile's launch row (before any wave leaves): r < 0 = this wave has no row.
-__device__ __forceinline__ void fused_test(const FusedTest &ft, int tl, int r, int e0, int deg, const int *__restrict__ col_idx,
-                                           const u64 *__restrict__ synd, int m, u64 dw)
+// Two halves, so that the atomics' round trips sit behind the wave's own row update instead of in front of it:
+// fused_row_parity at the top of the kernel (its index load and gather are in flight beside the row's message
+// loads), fused_commit at the bottom -- called by EVERY thread of EVERY block of the tile's launch row, rows or not.
+__device__ __forceinline__ u64 fused_row_parity(const FusedTest &ft, int tl, int r, int e0, int deg,
+                                                const int *__restrict__ col_idx, const u64 *__restrict__ synd, int m)
+{
+    if (r < 0) return 0;  // this wave has no row
+    const int lane = threadIdx.x & 63;
+    const u64 *bt = ft.hard + (size_t)tl * ft.n;
+    u64 x = 0;
+    for (int e = e0 + lane; e < e0 + deg; e += 64) x ^= bt[col_idx[e]];
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) x ^= __shfl_xor(x, off);
+    return x ^ synd[(size_t)tl * m + r];
+}
+
+__device__ __forceinline__ void fused_commit(const FusedTest &ft, int tl, u64 bad, u64 dw)
 {
     __shared__ u64 sbad[4];
     __shared__ int s_last;
     const int lane = threadIdx.x & 63;
-    u64 bad = 0;
-    if (r >= 0) {
-        const u64 *bt = ft.hard + (size_t)tl * ft.n;
-        u64 x = 0;
-        for (int e = e0 + lane; e < e0 + deg; e += 64) x ^= bt[col_idx[e]];
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) x ^= __shfl_xor(x, off);
-        bad = x ^ synd[(size_t)tl * m + r];
-    }
     if (lane == 0) sbad[threadIdx.x >> 6] = bad;
     __syncthreads();
     u64 *acc = ft.unsat + (size_t)tl * ft.pw;
@@ -531,25 +536,29 @@ __global__ __launch_bounds__(256) void k_check_minsum_x(const int *__restrict__ 
         if (skip_done && done[tl] == ~0ull) return;
     }
     const int r = md[0];
-    if constexpr (PAR) fused_test(ft, tl, r, md[1], md[2], col_idx, synd, m, dw);
-    if (r < 0) return;
-    const int e0 = md[1];
-    const int deg = md[2];
-    float *p = msg + ((size_t)tl * E + e0) * TW + lane;
-    const unsigned sbit = (unsigned)(synd[(size_t)tl * m + r] >> lane) & 1u;
+    u64 bad = 0;
+    if constexpr (PAR) bad = fused_row_parity(ft, tl, r, md[1], md[2], col_idx, synd, m);
+    if (!PAR && r < 0) return;
+    if (r >= 0) {
+        const int e0 = md[1];
+        const int deg = md[2];
+        float *p = msg + ((size_t)tl * E + e0) * TW + lane;
+        const unsigned sbit = (unsigned)(synd[(size_t)tl * m + r] >> lane) & 1u;
 #define MR(D)                                                                                   \
     case D:                                                                                     \
         if constexpr (D <= CAP) check_minsum_row<D, FIRST>(p, sbit, alpha, prior, col_idx + e0); \
         break;
 #define MR8(D) MR(D) MR(D + 1) MR(D + 2) MR(D + 3) MR(D + 4) MR(D + 5) MR(D + 6) MR(D + 7)
-    switch (deg) {
-        MR(1) MR(2) MR(3) MR(4) MR(5) MR(6) MR(7)
-        MR8(8) MR8(16) MR8(24) MR8(32) MR8(40) MR8(48) MR8(56)
-        MR(64)
-        default: break;
-    }
+        switch (deg) {
+            MR(1) MR(2) MR(3) MR(4) MR(5) MR(6) MR(7)
+            MR8(8) MR8(16) MR8(24) MR8(32) MR8(40) MR8(48) MR8(56)
+            MR(64)
+            default: break;
+        }
 #undef MR8
 #undef MR
+    }
+    if constexpr (PAR) fused_commit(ft, tl, bad, dw);
 }
 
 // ---------------------------------------------------------------------------
@@ -673,31 +682,35 @@ __global__ __launch_bounds__(256) void k_check_tanh(Buckets bk, const int *__res
         if (skip_done && done[tl] == ~0ull) return;
     }
     const int r = md[0];
-    if constexpr (PAR) fused_test(ft, tl, r, md[1], md[2], col_idx, synd, m, dw);
-    if (r < 0) return;
-    const int e0 = md[1];
-    const int deg = md[2];
-    const size_t base = ((size_t)tl * E + e0) * TW + lane;
-    float *p = msg + base;
-    const unsigned sbit = (unsigned)(synd[(size_t)tl * m + r] >> lane) & 1u;
-    // dispatch on the row's exact degree (wave-uniform); CAP bounds what is compiled in
+    u64 bad = 0;
+    if constexpr (PAR) bad = fused_row_parity(ft, tl, r, md[1], md[2], col_idx, synd, m);
+    if (!PAR && r < 0) return;
+    if (r >= 0) {
+        const int e0 = md[1];
+        const int deg = md[2];
+        const size_t base = ((size_t)tl * E + e0) * TW + lane;
+        float *p = msg + base;
+        const unsigned sbit = (unsigned)(synd[(size_t)tl * m + r] >> lane) & 1u;
+        // dispatch on the row's exact degree (wave-uniform); CAP bounds what is compiled in
 #define TR(D)                                                                              \
     case D:                                                                                \
         if constexpr (D <= CAP) check_tanh_row<D, FIRST>(p, sbit, prior, col_idx + e0);    \
         break;
 #define TR8(D) TR(D) TR(D + 1) TR(D + 2) TR(D + 3) TR(D + 4) TR(D + 5) TR(D + 6) TR(D + 7)
-    if (md[3] == 0) {
-        check_tanh_row_generic(p, scratch + base, deg, sbit);
-    } else {
-        switch (deg) {
-            TR(1) TR(2) TR(3) TR(4) TR(5) TR(6) TR(7)
-            TR8(8) TR8(16) TR8(24) TR8(32) TR8(40) TR8(48) TR8(56)
-            TR(64)
-            default: break;
+        if (md[3] == 0) {
+            check_tanh_row_generic(p, scratch + base, deg, sbit);
+        } else {
+            switch (deg) {
+                TR(1) TR(2) TR(3) TR(4) TR(5) TR(6) TR(7)
+                TR8(8) TR8(16) TR8(24) TR8(32) TR8(40) TR8(48) TR8(56)
+                TR(64)
+                default: break;
+            }
         }
-    }
 #undef TR8
 #undef TR
+    }
+    if constexpr (PAR) fused_commit(ft, tl, bad, dw);
 }
 
 // ---------------------------------------------------------------------------
