@@ -989,7 +989,7 @@ int iterate_tiles(scaldpc_bp *h, const TileState &st, int g0, int g, int max_ite
     if (first_fuse) SC_TRY(ensure_first_table(h, method, alpha_for(alpha, 1), s));
     // The convergence test of iteration it rides on the check pass of it + 1 (fused_test) wherever the host does not need
     // its verdict in between: at the iterations it polls at, stops a group at, or ends with, the stand-alone launch stays.
-    const bool ride = early && h->kn.fuse_finalize && h->kn.fuse_test && !ovl && check_can_test(h, method);
+    const bool ride = early && h->kn.fuse_finalize && h->kn.fuse_test && !ovl && check_can_test(h, method) && pw >= FT_WORDS;
     bool verdict_pending[MAX_LANES] = {};  // lane k's last variable pass has not been tested yet: its next check pass will
     bool set_phase = true;  // (re-)establish the one-kernel offset between neighbouring lanes
     for (int it = 1; it <= max_iter; it++) {

@@ -385,6 +385,12 @@ __device__ __forceinline__ u64 fused_row_parity(const FusedTest &ft, int tl, int
     return x ^ synd[(size_t)tl * m + r];
 }
 
+// A check launch has four times k_parity_fin's blocks per tile (1000 on the HQC-128 graph), and 1000 ORs plus 1000
+// tickets on ONE address each are ~12 us of serialised atomics per tile and iteration: accumulators and counters are
+// therefore SHARDED 16 ways by block index.  unsat words of a tile: [0] [1] k_parity_fin's pair (untouched here),
+// [2] top counter, [4 .. 19] shard accumulators, [20 .. 35] shard counters; all zero on entry and exit.
+constexpr int FT_SHARDS = 16, FT_WORDS = 36;
+
 __device__ __forceinline__ void fused_commit(const FusedTest &ft, int tl, u64 bad, u64 dw)
 {
     __shared__ u64 sbad[4];
@@ -392,27 +398,33 @@ __device__ __forceinline__ void fused_commit(const FusedTest &ft, int tl, u64 ba
     const int lane = threadIdx.x & 63;
     if (lane == 0) sbad[threadIdx.x >> 6] = bad;
     __syncthreads();
-    u64 *acc = ft.unsat + (size_t)tl * ft.pw;
+    u64 *w = ft.unsat + (size_t)tl * ft.pw;
     if (threadIdx.x == 0) {
+        const unsigned sh = blockIdx.x & (FT_SHARDS - 1);
+        const unsigned in_shard = (gridDim.x - sh + FT_SHARDS - 1) / FT_SHARDS;  // blocks of this launch row with this shard
+        const unsigned shards = gridDim.x < (unsigned)FT_SHARDS ? gridDim.x : (unsigned)FT_SHARDS;
         const u64 b = sbad[0] | sbad[1] | sbad[2] | sbad[3];
         if (b) {
-            const u64 old = atomicOr(acc, b);
+            const u64 old = atomicOr(w + 4 + sh, b);
             asm volatile("s_waitcnt vmcnt(0)" ::"v"((unsigned)old) : "memory");  // the OR is performed before the ticket is drawn
         }
-        const unsigned tk = atomicAdd((unsigned *)(acc + 1), 1u);
-        s_last = tk == gridDim.x - 1;
+        int last = 0;
+        if (atomicAdd((unsigned *)(w + 20 + sh), 1u) == in_shard - 1)  // the shard is complete: its OR holds every block's word
+            last = atomicAdd((unsigned *)(w + 2), 1u) == shards - 1;
+        s_last = last;
     }
     __syncthreads();
     if (!s_last || threadIdx.x >= 64) return;
+    // the tile's last block: gather the shards, latch (k_finalize), leave every word zero for the next launch
     const int c = threadIdx.x;
-    unsigned lo = 0, hi = 0;
-    if (c == 0) {
-        const u64 uw0 = atomicExch(acc, 0ull);
-        (void)atomicExch((unsigned *)(acc + 1), 0u);
-        lo = (unsigned)uw0;
-        hi = (unsigned)(uw0 >> 32);
+    u64 uw = 0;
+    if (c < FT_SHARDS) {
+        uw = atomicExch(w + 4 + c, 0ull);
+        (void)atomicExch((unsigned *)(w + 20 + c), 0u);
     }
-    const u64 uw = ((u64)(unsigned)rfl((int)hi) << 32) | (unsigned)rfl((int)lo);
+    if (c == 0) (void)atomicExch((unsigned *)(w + 2), 0u);
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) uw |= __shfl_xor(uw, off);
     const u64 newly = ~dw & ~uw;
     if ((newly >> c) & 1) ft.iters[(long)tl * TW + c] = ft.it_prev;
     if (c == 0) {

@@ -365,11 +365,11 @@ def test_convergence_test_riding_on_the_check_pass_is_invisible(oracle, method):
     H, Hin, probs, msg, y = hqc_instance(997, 9, 450, 6, 0.03, 700, seed=21)
     msg[:40, 997:] = H.syndrome(np.concatenate([y[:40], np.zeros((40, 450), np.uint8)], axis=1))  # noiseless checks: early convergers
     rng = np.random.RandomState(8)
-    Hd = (rng.rand(60, 150) < 0.07).astype(np.int8)
+    Hd = (rng.rand(160, 400) < 0.025).astype(np.int8)  # (the test rides on check passes of graphs with >= 136 rows)
     Hd[5] = 0  # an empty row: its syndrome bit alone decides
     G2 = S.TannerGraph.from_dense(Hd)
-    p2 = rng.uniform(0.01, 0.15, size=150)
-    s2 = G2.syndrome((rng.rand(200, 150) < p2[None, :]).astype(np.uint8))
+    p2 = rng.uniform(0.01, 0.1, size=400)
+    s2 = G2.syndrome((rng.rand(200, 400) < p2[None, :]).astype(np.uint8))
     for graph, pr, x, kind in ((H, probs, msg, "received_vector"), (G2, p2, s2, "syndrome")):
         outs = {}
         for ft in (1, 0):
