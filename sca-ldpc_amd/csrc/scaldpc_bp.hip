@@ -1002,7 +1002,7 @@ int iterate_tiles(scaldpc_bp *h, const TileState &st, int g0, int g, int max_ite
             FusedTest ft{};
             if (verdict_pending[k]) {
                 ft = FusedTest{st.hard + (size_t)ta * h->n, st.unsat + (size_t)ta * pw, st.done + ta, st.conv + ta,
-                               st.iters + (size_t)ta * TW, h->d_remaining + (it - 1), h->n, pw, it - 1};
+                               st.iters + (size_t)ta * TW, h->d_remaining + (it - 1), h->n, pw, it - 1, 1};
                 verdict_pending[k] = false;
             }
             SC_TRY(launch_check(h, method, alpha_for(alpha, it), gs[k], st.synd + (size_t)ta * h->m, st.done + ta, skip, lane[k],
@@ -1028,10 +1028,16 @@ int iterate_tiles(scaldpc_bp *h, const TileState &st, int g0, int g, int max_ite
                     SC_HIP(hipEventRecord(h->ev_var[k], lane[k]));
                     SC_HIP(hipStreamWaitEvent(ts, h->ev_var[k], 0));
                 }
-                hipLaunchKernelGGL(k_parity_fin, dim3((h->m + 4 * ROWS_PER_WAVE - 1) / (4 * ROWS_PER_WAVE), gs[k]), dim3(256), 0,
-                                   ts, h->d_row_ptr, h->d_col_idx, st.hard + (size_t)ta * h->n, h->m, h->n,
-                                   st.synd + (size_t)ta * h->m, st.unsat + (size_t)ta * pw, pw, it, early ? 1 : 0, st.done + ta,
-                                   st.conv + ta, st.iters + (size_t)ta * TW, h->d_remaining + it);
+                if (pw >= FT_WORDS && h->kn.fuse_test) {  // sharded accumulators / counters (fused_commit)
+                    const FusedTest pf{st.hard + (size_t)ta * h->n, st.unsat + (size_t)ta * pw, st.done + ta, st.conv + ta,
+                                       st.iters + (size_t)ta * TW, h->d_remaining + it, h->n, pw, it, early ? 1 : 0};
+                    hipLaunchKernelGGL(k_parity_fin_sharded, dim3((h->m + 4 * ROWS_PER_WAVE - 1) / (4 * ROWS_PER_WAVE), gs[k]),
+                                       dim3(256), 0, ts, h->d_row_ptr, h->d_col_idx, h->m, st.synd + (size_t)ta * h->m, pf);
+                } else
+                    hipLaunchKernelGGL(k_parity_fin, dim3((h->m + 4 * ROWS_PER_WAVE - 1) / (4 * ROWS_PER_WAVE), gs[k]), dim3(256), 0,
+                                       ts, h->d_row_ptr, h->d_col_idx, st.hard + (size_t)ta * h->n, h->m, h->n,
+                                       st.synd + (size_t)ta * h->m, st.unsat + (size_t)ta * pw, pw, it, early ? 1 : 0, st.done + ta,
+                                       st.conv + ta, st.iters + (size_t)ta * TW, h->d_remaining + it);
                 LAUNCH_CHECK();
                 if (ovl) {
                     SC_HIP(hipEventRecord(h->ev_test[k], ts));

@@ -367,6 +367,7 @@ struct FusedTest {
     int *iters;       // [tile][64]
     int *remaining;   // += codewords still running after the latch
     int n, pw, it_prev;
+    int latch;        // 1 = early exit (freeze newly converged codewords), 0 = fixed iterations (record the final verdict only)
 };
 
 // Two halves, so that the atomics' round trips sit behind the wave's own row update instead of in front of it:
@@ -426,13 +427,60 @@ __device__ __forceinline__ void fused_commit(const FusedTest &ft, int tl, u64 ba
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) uw |= __shfl_xor(uw, off);
     const u64 newly = ~dw & ~uw;
-    if ((newly >> c) & 1) ft.iters[(long)tl * TW + c] = ft.it_prev;
-    if (c == 0) {
-        ft.done[tl] = dw | newly;
-        ft.conv[tl] |= newly;
-        const int rem = __popcll(~(dw | newly));
-        if (rem) atomicAdd(ft.remaining, rem);
+    if (ft.latch) {
+        if ((newly >> c) & 1) ft.iters[(long)tl * TW + c] = ft.it_prev;
+        if (c == 0) {
+            ft.done[tl] = dw | newly;
+            ft.conv[tl] |= newly;
+            const int rem = __popcll(~(dw | newly));
+            if (rem) atomicAdd(ft.remaining, rem);
+        }
+    } else if (c == 0) {
+        ft.conv[tl] = newly;  // dw = padding here
     }
+}
+
+// k_parity_fin with the sharded accumulators / counters of fused_commit (tiles with at least FT_WORDS unsat words):
+// the stand-alone test's own 250 ORs + 250 tickets per tile on one address pair are ~6 us of its 15.
+// grid (ceil(m / (4*ROWS_PER_WAVE)), G), block 256; ft.it_prev = the iteration being tested.
+__global__ __launch_bounds__(256) void k_parity_fin_sharded(const int *__restrict__ row_ptr, const int *__restrict__ col_idx,
+                                                            int m, const u64 *__restrict__ synd, FusedTest ft)
+{
+    const int lane = threadIdx.x & 63;
+    const int t = blockIdx.y;
+    const u64 dw = ft.done[t];
+    if (dw == ~0ull) return;  // whole tile frozen (uniform over the launch row: no ticket is drawn for it)
+    const int wv = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int r0 = wv * ROWS_PER_WAVE;
+    const u64 *bt = ft.hard + (size_t)t * ft.n;
+    u64 bad = 0;
+    constexpr int IL = 4;
+    const int rend = min(r0 + ROWS_PER_WAVE, m);
+    for (int rb = r0; rb < rend; rb += IL) {
+        u64 a[IL];
+        int ea[IL], eb[IL];
+#pragma unroll
+        for (int i = 0; i < IL; i++) {
+            const int r = min(rb + i, rend - 1);
+            ea[i] = rfl(row_ptr[r]) + lane;
+            eb[i] = rb + i < rend ? rfl(row_ptr[r + 1]) : 0;
+        }
+#pragma unroll
+        for (int i = 0; i < IL; i++) a[i] = ea[i] < eb[i] ? bt[col_idx[ea[i]]] : 0ull;
+#pragma unroll
+        for (int i = 0; i < IL; i++)
+            for (int e = ea[i] + 64; e < eb[i]; e += 64) a[i] ^= bt[col_idx[e]];
+#pragma unroll
+        for (int i = 0; i < IL; i++) {
+            const int r = rb + i;
+            if (r >= rend) break;
+            u64 x = a[i];
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) x ^= __shfl_xor(x, off);
+            bad |= x ^ synd[(size_t)t * m + r];
+        }
+    }
+    fused_commit(ft, t, bad, dw);
 }
 
 // ---------------------------------------------------------------------------
