@@ -175,7 +175,7 @@ int scaldpc_bp_last_stats(scaldpc_bp *h, int64_t *out);
 /* Tuning / test knobs of one handle.  A new handle takes its defaults from the environment ONCE, at
  * creation (SCALDPC_PATH, SCALDPC_SPLIT, SCALDPC_GROUP_MB, SCALDPC_EL_MAX, SCALDPC_EL_FUSE,
  * SCALDPC_COMPACT_AFTER, SCALDPC_MINSUM_LOOP, SCALDPC_VAR_ORDER, SCALDPC_VAR_FORM, SCALDPC_SPECULATE,
- * SCALDPC_FUSE_FINALIZE, SCALDPC_TEST_OVERLAP, SCALDPC_FIRST_FUSED); the
+ * SCALDPC_FUSE_FINALIZE, SCALDPC_TEST_OVERLAP, SCALDPC_FIRST_FUSED, SCALDPC_FUSE_TEST); the
  * decode entry points never read
  * the environment.  key / value (text):
  *   "path"          "auto" | "stream" (64-codeword tiles) | "edge" (row-parallel up to 64) | "lds"
@@ -195,6 +195,9 @@ int scaldpc_bp_last_stats(scaldpc_bp *h, int64_t *out);
  *                   0 = every group polls
  *   "fuse_finalize" 1 (default) = convergence test and latch of the tile early-exit loop in one launch,
  *                   0 = two launches.
+ *   "fuse_test"     1 (default) = in the early-exit tile loop the convergence test of an iteration rides on the check
+ *                   pass of the next one (except where the host polls or stops), with sharded accumulators;
+ *                   0 = a stand-alone launch after every variable pass (SCALDPC_FUSE_TEST).
  *   "first_fused"   1 (default) = iteration 1 of the tile kernels runs without its check pass: the first variable
  *                   pass takes the first check-to-variable messages from a per-edge table (the message of a
  *                   zero-syndrome codeword) and the row's syndrome bit; 0 = check pass + plain variable pass
