@@ -101,6 +101,10 @@ struct scaldpc_bp {
         *d_unsat = nullptr;
     int *d_iters = nullptr, *d_remaining = nullptr;
     int cap_remaining = 0;
+    // d_remaining holds REM_SLOTS rows of cap_remaining "codewords still running after iteration it" counters: every tile
+    // group of a call takes the next row (zeroed once per call, not once per group: a memset is a 5 us launch in the
+    // group's dependency chain); rem_slot = next free row, REM_SLOTS = all used (the next taker zeroes the array)
+    int rem_slot = 0;
     bool post_alloc = false;
     // host-I/O staging
     uint8_t *d_in = nullptr, *d_out_bits = nullptr, *d_out_conv = nullptr;
@@ -302,6 +306,8 @@ int auto_group(const scaldpc_bp *h, int T)
 // waves per tile of a k_parity launch = words per tile of the unsat arrays
 int parity_waves(const scaldpc_bp *h) { return (h->m + 4 * ROWS_PER_WAVE - 1) / (4 * ROWS_PER_WAVE) * 4; }
 
+constexpr int REM_SLOTS = 512;
+
 int ensure_workspace(scaldpc_bp *h, int T, int G, bool want_post, int max_iter)
 {
     if (T > h->cap_tiles || h->m > h->ws_m || h->n > h->ws_n) {
@@ -334,10 +340,23 @@ int ensure_workspace(scaldpc_bp *h, int T, int G, bool want_post, int max_iter)
         cached_free(h->h_remaining);
         h->h_remaining = nullptr;
         h->cap_remaining = 0;
-        SC_TRY(dev_alloc(&h->d_remaining, (size_t)max_iter + 2));
+        SC_TRY(dev_alloc(&h->d_remaining, (size_t)REM_SLOTS * ((size_t)max_iter + 2)));
         SC_TRY(cached_alloc((void **)&h->h_remaining, sizeof(int) * ((size_t)max_iter + 2), true));
         h->cap_remaining = max_iter + 2;
     }
+    h->rem_slot = REM_SLOTS;  // a new call: the first tile group that needs counters zeroes the array
+    return 0;
+}
+
+// the next zeroed row of "still running" counters (the row-parallel and small-call paths keep using row 0 with a
+// memset of their own; they run between tile groups on the same stream)
+int next_remaining_row(scaldpc_bp *h, hipStream_t s, int **row)
+{
+    if (h->rem_slot >= REM_SLOTS) {
+        SC_HIP(hipMemsetAsync(h->d_remaining, 0, sizeof(int) * (size_t)REM_SLOTS * h->cap_remaining, s));
+        h->rem_slot = 1;  // (row 0 is the other paths')
+    }
+    *row = h->d_remaining + (size_t)h->rem_slot++ * h->cap_remaining;
     return 0;
 }
 
@@ -949,9 +968,10 @@ int iterate_tiles(scaldpc_bp *h, const TileState &st, int g0, int g, int max_ite
                            h->d_msg, h->E);
         LAUNCH_CHECK();
     }
-    if (early) SC_HIP(hipMemsetAsync(h->d_remaining, 0, sizeof(int) * ((size_t)max_iter + 2), s));
-    if (h->kn.fuse_finalize)  // k_parity_fin: accumulator and block counter of every tile of the group start at zero
-        SC_HIP(hipMemsetAsync(st.unsat + (size_t)g0 * pw, 0, sizeof(u64) * (size_t)g * pw, s));
+    int *rem = h->d_remaining;  // this group's row of "still running" counters
+    if (early) SC_TRY(next_remaining_row(h, s, &rem));
+    // (the accumulators / block counters of k_parity_fin and fused_commit are zeroed once per level, in decode_level,
+    // and every launch leaves them zero)
     if (nl > 1) {  // fork: the other lanes start after everything enqueued on `s` so far
         SC_HIP(hipEventRecord(h->ev_join[0], s));
         for (int k = 1; k < nl; k++) SC_HIP(hipStreamWaitEvent(lane[k], h->ev_join[0], 0));
@@ -1002,7 +1022,7 @@ int iterate_tiles(scaldpc_bp *h, const TileState &st, int g0, int g, int max_ite
             FusedTest ft{};
             if (verdict_pending[k]) {
                 ft = FusedTest{st.hard + (size_t)ta * h->n, st.unsat + (size_t)ta * pw, st.done + ta, st.conv + ta,
-                               st.iters + (size_t)ta * TW, h->d_remaining + (it - 1), h->n, pw, it - 1, 1};
+                               st.iters + (size_t)ta * TW, rem + (it - 1), h->n, pw, it - 1, 1};
                 verdict_pending[k] = false;
             }
             SC_TRY(launch_check(h, method, alpha_for(alpha, it), gs[k], st.synd + (size_t)ta * h->m, st.done + ta, skip, lane[k],
@@ -1030,14 +1050,14 @@ int iterate_tiles(scaldpc_bp *h, const TileState &st, int g0, int g, int max_ite
                 }
                 if (pw >= FT_WORDS && h->kn.fuse_test) {  // sharded accumulators / counters (fused_commit)
                     const FusedTest pf{st.hard + (size_t)ta * h->n, st.unsat + (size_t)ta * pw, st.done + ta, st.conv + ta,
-                                       st.iters + (size_t)ta * TW, h->d_remaining + it, h->n, pw, it, early ? 1 : 0};
+                                       st.iters + (size_t)ta * TW, rem + it, h->n, pw, it, early ? 1 : 0};
                     hipLaunchKernelGGL(k_parity_fin_sharded, dim3((h->m + 4 * ROWS_PER_WAVE - 1) / (4 * ROWS_PER_WAVE), gs[k]),
                                        dim3(256), 0, ts, h->d_row_ptr, h->d_col_idx, h->m, st.synd + (size_t)ta * h->m, pf);
                 } else
                     hipLaunchKernelGGL(k_parity_fin, dim3((h->m + 4 * ROWS_PER_WAVE - 1) / (4 * ROWS_PER_WAVE), gs[k]), dim3(256), 0,
                                        ts, h->d_row_ptr, h->d_col_idx, st.hard + (size_t)ta * h->n, h->m, h->n,
                                        st.synd + (size_t)ta * h->m, st.unsat + (size_t)ta * pw, pw, it, early ? 1 : 0, st.done + ta,
-                                       st.conv + ta, st.iters + (size_t)ta * TW, h->d_remaining + it);
+                                       st.conv + ta, st.iters + (size_t)ta * TW, rem + it);
                 LAUNCH_CHECK();
                 if (ovl) {
                     SC_HIP(hipEventRecord(h->ev_test[k], ts));
@@ -1050,7 +1070,7 @@ int iterate_tiles(scaldpc_bp *h, const TileState &st, int g0, int g, int max_ite
                                    (const u64 *)(st.done + ta));
                 LAUNCH_CHECK();
                 hipLaunchKernelGGL(k_finalize, dim3(gs[k]), dim3(64), 0, lane[k], it, early ? 1 : 0, st.done + ta, st.conv + ta,
-                                   st.unsat + (size_t)ta * pw, pw, st.iters + (size_t)ta * TW, h->d_remaining + it);
+                                   st.unsat + (size_t)ta * pw, pw, st.iters + (size_t)ta * TW, rem + it);
                 LAUNCH_CHECK();
             }
         }
@@ -1064,7 +1084,7 @@ int iterate_tiles(scaldpc_bp *h, const TileState &st, int g0, int g, int max_ite
         }
         if (early && !last && poll) {
             SC_TRY(join());
-            SC_HIP(hipMemcpyAsync(h->h_remaining + it, h->d_remaining + it, sizeof(int), hipMemcpyDeviceToHost, s));
+            SC_HIP(hipMemcpyAsync(h->h_remaining + it, rem + it, sizeof(int), hipMemcpyDeviceToHost, s));
             SC_HIP(hipStreamSynchronize(s));
             set_phase = true;
             const int rem = h->h_remaining[it];
@@ -1162,6 +1182,8 @@ int decode_level(scaldpc_bp *h, int lvl, const TileState &st, int batch, int T, 
         if (h->kn.compact_after >= 0) defer_after = h->kn.compact_after;
         if (max_iter <= 2 * defer_after) defer_after = 0;  // nothing to gain
     }
+    if (!el && h->kn.fuse_finalize)  // accumulators and block counters of the convergence tests: zero once, every launch leaves them zero
+        SC_HIP(hipMemsetAsync(st.unsat, 0, sizeof(u64) * (size_t)T * parity_waves(h), s));
     std::vector<char> deferred_tile(T, 0);
     bool any = false;
     PollState poll_hint;
