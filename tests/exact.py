@@ -14,7 +14,6 @@ Nothing here looks at messages, schedules or kernels: the definitions are
   q-ary        x*  = argmin_{x: sum_j H[c,j] x_j = 0 over the INTEGERS for every check c} sum_v llr_v[x_v]
 with P(e) = prod_j p_j^e_j (1-p_j)^(1-e_j) (the per-bit priors of ldpc.bp_decoder's channel_probs).
 """
-import itertools
 
 import numpy as np
 
