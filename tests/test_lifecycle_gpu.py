@@ -98,7 +98,7 @@ CHILD = r"""
 import importlib, json, os, sys
 import numpy as np
 sys.path.insert(0, sys.argv[1]); sys.path.insert(0, os.path.join(sys.argv[1], "tests"))
-from helpers import S, hqc_instance
+from helpers import ORACLE_METHOD, S, compare, hqc_instance
 from oracle import pyoracle
 bp = importlib.import_module("sca-ldpc_amd.bp"); qary = importlib.import_module("sca-ldpc_amd.qary")
 lib = importlib.import_module("sca-ldpc_amd._lib")
