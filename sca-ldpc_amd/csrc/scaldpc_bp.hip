@@ -751,10 +751,11 @@ int launch_var(scaldpc_bp *h, int G, float *post_g, u64 *hard_g, const u64 *done
     float *const msg0 = h->d_msg + (size_t)tile0 * h->E * TW;
     float *const scr0 = h->d_scratch ? h->d_scratch + (size_t)tile0 * h->E * TW : nullptr;
     if (first_synd) {
+        const int nrec = 4 * h->var_bk.blk[h->var_bk.nb];  // one record per wave of a plain k_var launch; two per wave here
+        const dim3 grid2((unsigned)((nrec + 7) / 8), G);
 #define VAR_FIRST(CAP)                                                                                              \
-    hipLaunchKernelGGL((k_var<CAP, 1, true>), grid, dim3(256), 0, s, h->var_bk, h->d_var_meta, h->d_col_ptr, h->d_csc_list, \
-                       h->d_prior, msg0, scr0, post_g, hard_g, done_g, skip_done, h->n, h->E, write_out,            \
-                       (const int2 *)h->d_first_tab, first_synd, h->m)
+    hipLaunchKernelGGL((k_var_first<CAP>), grid2, dim3(256), 0, s, h->d_var_meta, h->d_csc_list, h->d_prior, msg0, post_g,  \
+                       hard_g, done_g, skip_done, h->n, h->E, write_out, (const int2 *)h->d_first_tab, first_synd, h->m, nrec)
         if (h->max_col_deg <= 16)
             VAR_FIRST(16);
         else if (h->max_col_deg <= 32)

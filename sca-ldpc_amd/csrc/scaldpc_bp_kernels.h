@@ -1027,10 +1027,11 @@ __device__ __forceinline__ float var_col_s(float *tile_base, unsigned lane, cons
 // loads instead of gathering 256-B message rows a check pass would have had to write first: one launch and
 // 8 E bytes per codeword less, same sums in the same order, identical results.
 //   ft: the column's slice of first_tab (laid out like the re-laid edge list), {message bits, row}
+//   f, wv: lane j's table entry of the column's j-th edge and that edge's syndrome word (fetched by the kernel, for
+//          BOTH columns a wave handles, before either is processed)
 template <int MAXD>
 __device__ __forceinline__ float var_col_first(float *tile_base, unsigned lane, const int4 *__restrict__ rec4,
-                                               const int *__restrict__ ce1, const int2 *__restrict__ ft,
-                                               const u64 *__restrict__ synd_t, int d, float pr)
+                                               const int *__restrict__ ce1, int2 f, u64 wv, int d, float pr)
 {
     int eid[MAXD];
     {
@@ -1047,9 +1048,6 @@ __device__ __forceinline__ float var_col_first(float *tile_base, unsigned lane, 
     // (Through scalar loads the compiler makes every edge its own dependent `s_load; s_waitcnt; s_load; s_waitcnt`
     // chain -- 22 round trips in a row for a degree-11 column -- or, with the loads hoisted out of the `k < d`
     // predicate, still one `s_load; s_waitcnt` per syndrome word for want of SGPRs.)
-    int2 f = make_int2(0, 0);
-    if ((int)lane < d) f = ft[lane];
-    const u64 wv = synd_t[f.y];  // (lanes >= d read row 0: valid, unused)
     const int wlo = (int)(unsigned)wv, whi = (int)(unsigned)(wv >> 32);
 #pragma unroll
     for (int k = 0; k < MAXD; k++)
@@ -1116,16 +1114,13 @@ __device__ __forceinline__ float var_col_generic(float *mt, float *st, const int
 // write_out: also emit hard-decision planes (merged under the done mask) and, if
 // `post` is non-null, the posterior of every not-yet-frozen codeword.
 // CAP = largest unroll bound compiled in (see k_check_tanh).
-// FIRST (with FORM 1 only): iteration 1 straight from first_tab and the syndrome planes (var_col_first); every column
-// of the graph has a register-resident degree then (the host checks: max column degree <= 64).
-template <int CAP, int FORM = 0, bool FIRST = false>
+template <int CAP, int FORM = 0>
 __global__ __launch_bounds__(256) void k_var(Buckets bk, const int *__restrict__ list,
                                              const int *__restrict__ col_ptr, const int *__restrict__ csc_edge,
                                              const float *__restrict__ prior, float *msg, float *scratch,
                                              float *__restrict__ post, u64 *__restrict__ hard,
                                              const u64 *__restrict__ done, int skip_done, int n, long E,
-                                             int write_out, const int2 *__restrict__ first_tab = nullptr,
-                                             const u64 *__restrict__ synd = nullptr, int m = 0)
+                                             int write_out)
 {
     const int lane = threadIdx.x & 63;
     const int tl = blockIdx.y;
@@ -1144,27 +1139,7 @@ __global__ __launch_bounds__(256) void k_var(Buckets bk, const int *__restrict__
     const int *ce = csc_edge + cb, *ce0 = rec + 4;
     const float pr = prior[v];
     float L = pr;
-    if constexpr (FORM == 1 && FIRST) {
-        float *tb = msg + (size_t)tl * E * TW;
-        const unsigned ul = threadIdx.x & 63u;
-        const int4 *r4 = (const int4 *)rec;
-        const int2 *ft = first_tab + cb;
-        const u64 *st = synd + (size_t)tl * m;
-        switch (rec[3]) {
-            case 1: L = var_col_first<1>(tb, ul, r4, ce, ft, st, d, pr); break;
-            case 2: L = var_col_first<2>(tb, ul, r4, ce, ft, st, d, pr); break;
-            case 4: L = var_col_first<4>(tb, ul, r4, ce, ft, st, d, pr); break;
-            case 8: L = var_col_first<8>(tb, ul, r4, ce, ft, st, d, pr); break;
-            case 16: L = var_col_first<16>(tb, ul, r4, ce, ft, st, d, pr); break;
-            case 32:
-                if constexpr (CAP >= 32) L = var_col_first<32>(tb, ul, r4, ce, ft, st, d, pr);
-                break;
-            case 64:
-                if constexpr (CAP >= 64) L = var_col_first<64>(tb, ul, r4, ce, ft, st, d, pr);
-                break;
-            default: break;  // (no any-degree columns when this instantiation is launched)
-        }
-    } else if constexpr (FORM == 1) {
+    if constexpr (FORM == 1) {
         float *tb = msg + (size_t)tl * E * TW;
         const unsigned ul = threadIdx.x & 63u;  // unsigned lane index: lets the gathers take the SGPR-base form
         const int4 *r4 = (const int4 *)rec;
@@ -1202,6 +1177,74 @@ __global__ __launch_bounds__(256) void k_var(Buckets bk, const int *__restrict__
         const size_t hi = (size_t)tl * n + v;
         if (lane == 0) hard[hi] = (hard[hi] & dn) | (hb & ~dn);
         if (post && !((dn >> lane) & 1)) post[hi * TW + lane] = L;
+    }
+}
+
+// ITERATION 1 of the tile kernels (see var_col_first): every wave takes TWO column records of the launch order and
+// fetches both columns' table entries, then both columns' syndrome words, before it processes either -- the pass is
+// three dependent round trips around half a pass's bytes, so a second column in flight per wave is what shortens it
+// (one column per wave: 46.9 us per 128-codeword launch on the HQC-128 graph).  Every column of the graph has a
+// register-resident degree (the host checks: max column degree <= 64), records come in fours, hence in pairs.
+// grid (ceil(nrec / 8), G), block 256 = 4 waves = 8 records.
+template <int CAP>
+__global__ __launch_bounds__(256) void k_var_first(const int *__restrict__ list, const int *__restrict__ csc_edge,
+                                                   const float *__restrict__ prior, float *msg, float *__restrict__ post,
+                                                   u64 *__restrict__ hard, const u64 *__restrict__ done, int skip_done, int n,
+                                                   long E, int write_out, const int2 *__restrict__ first_tab,
+                                                   const u64 *__restrict__ synd, int m, int nrec)
+{
+    const unsigned lane = threadIdx.x & 63u;
+    const int tl = blockIdx.y;
+    const int r0 = 2 * rfl((int)blockIdx.x * 4 + (int)(threadIdx.x >> 6));
+    if (r0 >= nrec) return;
+    const u64 dn = done[tl];
+    if (skip_done && dn == ~0ull) return;
+    float *tb = msg + (size_t)tl * E * TW;
+    const u64 *st = synd + (size_t)tl * m;
+    const int *rec[2] = {list + (size_t)r0 * VAR_REC, list + (size_t)(r0 + 1) * VAR_REC};
+    int v[2], cb[2], d[2];
+    int2 f[2];
+    u64 wv[2];
+    float pr[2];
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+        v[j] = rec[j][0];
+        cb[j] = rec[j][1];
+        d[j] = v[j] < 0 ? 0 : rec[j][2];
+        f[j] = make_int2(0, 0);
+        if ((int)lane < d[j]) f[j] = first_tab[(size_t)cb[j] + lane];
+    }
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+        wv[j] = st[f[j].y];  // (lanes >= d read row 0: valid, unused)
+        pr[j] = prior[v[j] < 0 ? 0 : v[j]];
+    }
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+        if (v[j] < 0) continue;  // padding record
+        const int4 *r4 = (const int4 *)rec[j];
+        const int *ce = csc_edge + cb[j];
+        float L = pr[j];
+        switch (rec[j][3]) {
+            case 1: L = var_col_first<1>(tb, lane, r4, ce, f[j], wv[j], d[j], pr[j]); break;
+            case 2: L = var_col_first<2>(tb, lane, r4, ce, f[j], wv[j], d[j], pr[j]); break;
+            case 4: L = var_col_first<4>(tb, lane, r4, ce, f[j], wv[j], d[j], pr[j]); break;
+            case 8: L = var_col_first<8>(tb, lane, r4, ce, f[j], wv[j], d[j], pr[j]); break;
+            case 16: L = var_col_first<16>(tb, lane, r4, ce, f[j], wv[j], d[j], pr[j]); break;
+            case 32:
+                if constexpr (CAP >= 32) L = var_col_first<32>(tb, lane, r4, ce, f[j], wv[j], d[j], pr[j]);
+                break;
+            case 64:
+                if constexpr (CAP >= 64) L = var_col_first<64>(tb, lane, r4, ce, f[j], wv[j], d[j], pr[j]);
+                break;
+            default: break;  // (no any-degree columns when this kernel is launched)
+        }
+        if (write_out) {
+            const u64 hb = __ballot(L <= 0.0f);
+            const size_t hi = (size_t)tl * n + v[j];
+            if (lane == 0) hard[hi] = (hard[hi] & dn) | (hb & ~dn);
+            if (post && !((dn >> lane) & 1)) post[hi * TW + lane] = L;
+        }
     }
 }
 
