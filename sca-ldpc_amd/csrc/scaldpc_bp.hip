@@ -74,7 +74,7 @@ struct Knobs {
     int fuse_finalize = 1;    // tile early-exit loop: convergence test and latch in one launch (k_parity_fin); 0 = k_parity + k_finalize
     int speculate = 1;        // early-exit tile groups: stop at the hand-over point without polling once two groups in a row did (0 = always poll)
     int fuse_test = 1;        // early-exit tile loop: the convergence test of iteration it rides on the check pass of it + 1 wherever the host does not need the verdict in between
-    int first_fused = 1;      // iteration 1 of the tile kernels without its check pass (k_var<.., FIRST> from the first-message table); 0 = check pass + plain variable pass
+    int first_fused = 1;      // iteration 1 of the tile kernels without its check pass (k_var_first from the first-message table); 0 = check pass + plain variable pass
     int test_overlap = 0;     // early-exit tile groups: 1 = the convergence test of iteration it runs on a side stream beside the check pass of it + 1 (A/B knob: measured 3.4 % SLOWER on the config-5 sweep, profiles/r03/ab_test_overlap.log)
     int var_form = 1;         // k_var: 0 = ids fetched edge by edge, 1 = all ids up front as wide scalar loads (default)
 };
@@ -690,7 +690,7 @@ int launch_check(scaldpc_bp *h, int method, float alpha, int G, const u64 *synd_
     return 0;
 }
 
-// Can iteration 1 run without its check pass (k_var<.., FIRST>)?  The first messages come from the row-parallel check
+// Can iteration 1 run without its check pass (k_var_first)?  The first messages come from the row-parallel check
 // kernel (rows of at most 64 edges), the first variable pass keeps every column in registers (columns of at most 64).
 bool first_fusable(const scaldpc_bp *h, int method)
 {
