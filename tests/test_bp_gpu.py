@@ -269,6 +269,31 @@ def test_bench_configuration_against_oracle(oracle, method, decode_path):
     assert 0.7 < ok.mean() < 0.95  # the bench line's decode_success_rate (0.81 at eps = 0.05)
 
 
+def test_hqc192_bench_graph_sample(oracle, decode_path):
+    """The HQC-192 shape SURVEY 8(d) reports beside the BASELINE configs (N = 35 851, R = 8000, E = 408 000, omega = 100):
+    min-sum, 50 fixed iterations, three two-tile groups; 36 codewords from the first, a middle and the last tile against
+    the oracle, bit for bit incl. posteriors."""
+    if decode_path != "auto":
+        pytest.skip("the library's own schedule")
+    import json, os
+
+    trials = importlib.import_module("sca-ldpc_amd.trials")
+    rows = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "hqc_first_rows.json")))
+    H, Hin, _ = S.codes.hqc_bench_graph("hqc192", rows["N35851_W50_s0"])
+    assert (H.m, H.n, H.nnz) == (8000, 43851, 408000)
+    N, omega = S.codes.HQC_PARAMS["hqc192"]
+    eps, batch = 0.05, 384
+    probs = trials.hqc_priors(N, Hin.m, omega, eps)
+    msg, ys = trials.hqc_trials(Hin, omega, eps, batch, base_seed=2, first_index=0)
+    dec = bp.bp_decoder(H, max_iter=50, bp_method="min_sum", channel_probs=probs)
+    got = dec.decode_batch(msg, early_exit=False, want_llr=True)
+    dec.close()
+    pick = np.r_[0:12, 192:204, 372:384]
+    ref = oracle.bp_decode_batch(H, probs, msg[pick], 1, 50, "min_sum", dtype="f32", threads=12, early_exit=False)
+    compare({k: v[pick] for k, v in got.items()}, ref, "min_sum")
+    assert 0.4 < trials.success(got["bits"], ys, N).mean() < 0.9  # (the bench line: 0.65)
+
+
 def test_hqc256_bench_configuration(oracle, decode_path):
     """BASELINE config 3 at its STATED batch -- what `bench.py --workload hqc256_tanh` times: the HQC-256 graph
     (12 000 x 69 637, E = 612 000), batch 4096, 50 FIXED iterations, tanh rule, device I/O on the caller's
