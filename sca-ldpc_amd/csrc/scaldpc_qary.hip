@@ -349,10 +349,13 @@ __device__ __forceinline__ void q_check_unrolled(float *msg, int e0, long Bp, lo
         for (int q = 0; q < Q; q++) msg[((size_t)(e0 + j) * Q + q) * Bp + b] = Bt[j][q];
 }
 
-// grid (R, Bp/256), block 256.
-template <int Q, int KMAX>
-__global__ __launch_bounds__(256) void k_q_check_unrolled(const int *__restrict__ row_ptr, float *msg, long Bp, int batch,
-                                                          int *__restrict__ err)
+// grid (R, Bp/64), block 64.  OCC = waves per SIMD the register allocation aims at (amdgpu_waves_per_eu): left alone the
+// compiler spends 294 registers on the 108 KB of straight-line code (one wave per SIMD, no spill), and a launch of
+// 2400 waves (config 4: 150 checks x 1024 codewords) then takes THREE rounds of 1024 where 2.34 would do -- the time per
+// launch is a staircase in the batch size (37 / 53.5 / 69 / 84 us at 1650 / 2400 / 3300 / 4800 waves, measured).
+template <int Q, int KMAX, int OCC>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(OCC, OCC))) void k_q_check_unrolled(
+    const int *__restrict__ row_ptr, float *msg, long Bp, int batch, int *__restrict__ err)
 {
     const int c = blockIdx.x;
     const long b = (long)blockIdx.y * blockDim.x + threadIdx.x;
@@ -781,6 +784,7 @@ struct scaldpc_qary {
     int kn_tree = 1;     // special decoder: tree-walk check kernel for the Kyber shape (QB = 5, 6 coefficient edges)
     // measurement aid (bench.py): with "timing" = 1 every check / variable launch of a call is bracketed by HIP events
     // on the launch stream; scaldpc_qary_last_timing reads the sums.  Off by default: the product path records nothing.
+    int kn_occ = 2;      // unrolled enumeration: waves per SIMD the kernel is compiled for (1 .. 4; A/B knob "occ")
     int kn_timing = 0;
     std::vector<hipEvent_t> tev;
     float stat_ms_check = 0.f, stat_ms_var = 0.f, stat_ms_call = 0.f;
@@ -884,6 +888,7 @@ int qary_build(int R, int N, int B, int BSUM, bool special, const int8_t *H, int
     if (!rc && hipGetDevice(&h->device) != hipSuccess) rc = fail(SCALDPC_EHIP, "hipGetDevice failed");
     if (const char *e = getenv("SCALDPC_QARY_WAVE")) h->kn_wave = atoi(e) != 0;  // the environment is read once per handle
     if (getenv("SCALDPC_QARY_NO_UNROLL")) h->kn_unroll = 0;
+    if (const char *o = getenv("SCALDPC_QARY_OCC")) h->kn_occ = std::max(1, std::min(4, atoi(o)));
     if (getenv("SCALDPC_QARY_NO_TREE")) h->kn_tree = 0;
     if (!rc && hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking) != hipSuccess)
         rc = fail(SCALDPC_EHIP, "hipStreamCreate failed");
@@ -996,12 +1001,25 @@ int qary_run(scaldpc_qary *h, const float *pmf_b, const float *pmf_s, int batch,
     for (int it = 1; it <= iters; it++) {
         if (timing) SC_HIP(hipEventRecord(h->tev[2 * (it - 1)], s));
         if (h->E) {
-            if (unrolled == 3)
-                hipLaunchKernelGGL((k_q_check_unrolled<3, 7>), dim3(h->R, Bp / 64), dim3(64), 0, s, h->d_row_ptr, h->d_msg, Bp,
-                                   batch, h->d_err);
-            else if (unrolled == 5)
-                hipLaunchKernelGGL((k_q_check_unrolled<5, 5>), dim3(h->R, Bp / 64), dim3(64), 0, s, h->d_row_ptr, h->d_msg, Bp,
-                                   batch, h->d_err);
+#define QUNROLLED(QQ, KK, OCC)                                                                                    \
+    hipLaunchKernelGGL((k_q_check_unrolled<QQ, KK, OCC>), dim3(h->R, Bp / 64), dim3(64), 0, s, h->d_row_ptr, h->d_msg, Bp, \
+                       batch, h->d_err)
+            if (unrolled == 3) {
+                switch (h->kn_occ) {
+                    case 1: QUNROLLED(3, 7, 1); break;
+                    case 3: QUNROLLED(3, 7, 3); break;
+                    case 4: QUNROLLED(3, 7, 4); break;
+                    default: QUNROLLED(3, 7, 2); break;
+                }
+            } else if (unrolled == 5) {
+                switch (h->kn_occ) {
+                    case 1: QUNROLLED(5, 5, 1); break;
+                    case 3: QUNROLLED(5, 5, 3); break;
+                    case 4: QUNROLLED(5, 5, 4); break;
+                    default: QUNROLLED(5, 5, 2); break;
+                }
+            }
+#undef QUNROLLED
             else if (h->special && tree_nb) {
                 // the Kyber shape: tree walk for the rows of 6 coefficient edges, the generic wave kernel for any others
                 const size_t tree_lds = ((size_t)tree_nb * h->Q + h->QS + (size_t)(tree_nb * h->Q + h->QS) * 64) * 4;
@@ -1147,6 +1165,8 @@ int scaldpc_qary_configure(scaldpc_qary *h, const char *key, const char *value)
         h->kn_tree = atoi(value) != 0;
     else if (!strcmp(key, "timing"))
         h->kn_timing = atoi(value) != 0;
+    else if (!strcmp(key, "occ"))
+        h->kn_occ = std::max(1, std::min(4, atoi(value)));
     else
         return fail(SCALDPC_EINVAL, "unknown knob %s", key);
     return 0;
