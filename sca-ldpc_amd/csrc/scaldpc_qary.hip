@@ -751,6 +751,71 @@ __global__ void k_q_var(int v0, const int *__restrict__ col_ptr, const int *__re
     }
 }
 
+// The same update with everything in registers, for the plain decoder with a small alphabet (Q = 3, 5) and columns of at
+// most DMAX checks: every incoming message is loaded ONCE (the generic kernel reads each twice, with an LDS round trip
+// between global accesses), all of a column's loads are issued before the first add.  Same additions and subtractions in
+// the same order, the same first-minimum rule: identical symbols.  llr is [var][Q][Bp] here (one alphabet).
+// grid (N, Bp/64), block 64.
+template <int Q, int DMAX>
+__global__ __launch_bounds__(64) void k_q_var_small(const int *__restrict__ col_ptr, const int *__restrict__ csc_edge,
+                                                    const int *__restrict__ edge_h, const float *__restrict__ llr, float *msg,
+                                                    long Bp, int batch, int last, signed char *__restrict__ out)
+{
+    const int v = blockIdx.x;
+    const long b = (long)blockIdx.y * 64 + threadIdx.x;
+    if (b >= batch) return;
+    const int c0 = col_ptr[v], deg = col_ptr[v + 1] - c0;
+    float sum[Q], in[DMAX][Q];
+    int ed[DMAX];
+    bool rv[DMAX];
+#pragma unroll
+    for (int q = 0; q < Q; q++) sum[q] = llr[((size_t)v * Q + q) * Bp + b];
+#pragma unroll
+    for (int t = 0; t < DMAX; t++) {
+        ed[t] = 0;
+        rv[t] = false;
+        if (t < deg) {
+            ed[t] = csc_edge[c0 + t];
+            rv[t] = edge_h[ed[t]] < 0;
+#pragma unroll
+            for (int q = 0; q < Q; q++) in[t][q] = msg[((size_t)ed[t] * Q + q) * Bp + b];
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < DMAX; t++)
+        if (t < deg) {
+#pragma unroll
+            for (int q = 0; q < Q; q++) sum[q] = sum[q] + (rv[t] ? in[t][Q - 1 - q] : in[t][q]);
+        }
+#pragma unroll
+    for (int t = 0; t < DMAX; t++)
+        if (t < deg) {
+            float tmp[Q];  // tmp[qi] = sum[q] - c2v[qi], qi = q mirrored where h < 0
+#pragma unroll
+            for (int q = 0; q < Q; q++) tmp[q] = (rv[t] ? sum[Q - 1 - q] : sum[q]) - in[t][q];
+            float mv = INFINITY, mn = tmp[0];  // first strict minimum; default index 0 (NaN never selected)
+#pragma unroll
+            for (int q = 0; q < Q; q++)
+                if (tmp[q] < mv) {
+                    mv = tmp[q];
+                    mn = tmp[q];
+                }
+#pragma unroll
+            for (int q = 0; q < Q; q++) msg[((size_t)ed[t] * Q + q) * Bp + b] = tmp[q] - mn;
+        }
+    if (last) {
+        float mv = INFINITY;
+        int ma = 0;
+#pragma unroll
+        for (int q = 0; q < Q; q++)
+            if (sum[q] < mv) {
+                mv = sum[q];
+                ma = q;
+            }
+        out[(size_t)v * Bp + b] = (signed char)(ma - (Q - 1) / 2);
+    }
+}
+
 // [N][Bp] -> [batch][N]
 __global__ void k_q_unpack(const signed char *__restrict__ in, int N, int batch, long Bp, signed char *__restrict__ out)
 {
@@ -764,7 +829,7 @@ __global__ void k_q_unpack(const signed char *__restrict__ in, int N, int batch,
 struct scaldpc_qary {
     bool special = false;
     int R = 0, N = 0, B = 0, BSUM = 0, Q = 0, QS = 0, W = 0, iterations = 0;
-    int E = 0, maxdc = 0, mindc = 0;
+    int E = 0, maxdc = 0, mindc = 0, maxdv = 0;
     long llr_rows = 0;  // total alphabet rows over all variables
     int *d_row_ptr = nullptr, *d_col_ptr = nullptr, *d_csc_edge = nullptr, *d_edge_var = nullptr, *d_edge_h = nullptr,
         *d_var_q = nullptr;
@@ -784,6 +849,7 @@ struct scaldpc_qary {
     int kn_tree = 1;     // special decoder: tree-walk check kernel for the Kyber shape (QB = 5, 6 coefficient edges)
     // measurement aid (bench.py): with "timing" = 1 every check / variable launch of a call is bracketed by HIP events
     // on the launch stream; scaldpc_qary_last_timing reads the sums.  Off by default: the product path records nothing.
+    int kn_var_small = 1;  // register-resident variable update for Q = 3 / 5 and columns of at most 4 checks (A/B knob "var_small")
     int kn_occ = 2;      // unrolled enumeration: waves per SIMD the kernel is compiled for (1 .. 4; A/B knob "occ")
     int kn_timing = 0;
     std::vector<hipEvent_t> tev;
@@ -858,6 +924,7 @@ int qary_build(int R, int N, int B, int BSUM, bool special, const int8_t *H, int
     h->E = E;
     h->maxdc = maxdc;
     h->mindc = maxdc;
+    for (int v = 0; v < N; v++) h->maxdv = std::max(h->maxdv, col_cnt[v]);
     for (int r = 0; r < R; r++) h->mindc = std::min(h->mindc, row_ptr[r + 1] - row_ptr[r]);
     h->h_var_q.resize(N);
     h->h_var_off.resize(N);
@@ -1047,9 +1114,18 @@ int qary_run(scaldpc_qary *h, const float *pmf_b, const float *pmf_s, int batch,
             SC_HIP(hipGetLastError());
         }
         if (timing) SC_HIP(hipEventRecord(h->tev[2 * (it - 1) + 1], s));
-        hipLaunchKernelGGL(k_q_var, dim3(h->N, Bp / TB), dim3(TB), (size_t)2 * h->W * TB * 4, s, 0, h->d_col_ptr,
-                           h->d_csc_edge, h->d_edge_h, h->d_var_q, h->d_var_off, h->d_llr, h->d_msg, h->W, Bp, batch, h->W,
-                           it == iters ? 1 : 0, h->d_hard);
+#define QVAR_SMALL(QQ)                                                                                              \
+    hipLaunchKernelGGL((k_q_var_small<QQ, 4>), dim3(h->N, Bp / 64), dim3(64), 0, s, h->d_col_ptr, h->d_csc_edge, h->d_edge_h, \
+                       h->d_llr, h->d_msg, Bp, batch, it == iters ? 1 : 0, h->d_hard)
+        if (!h->special && h->kn_var_small && h->maxdv <= 4 && h->Q == 3)
+            QVAR_SMALL(3);
+        else if (!h->special && h->kn_var_small && h->maxdv <= 4 && h->Q == 5)
+            QVAR_SMALL(5);
+        else
+            hipLaunchKernelGGL(k_q_var, dim3(h->N, Bp / TB), dim3(TB), (size_t)2 * h->W * TB * 4, s, 0, h->d_col_ptr,
+                               h->d_csc_edge, h->d_edge_h, h->d_var_q, h->d_var_off, h->d_llr, h->d_msg, h->W, Bp, batch, h->W,
+                               it == iters ? 1 : 0, h->d_hard);
+#undef QVAR_SMALL
         SC_HIP(hipGetLastError());
     }
     if (timing) SC_HIP(hipEventRecord(h->tev[2 * iters], s));
@@ -1165,6 +1241,8 @@ int scaldpc_qary_configure(scaldpc_qary *h, const char *key, const char *value)
         h->kn_tree = atoi(value) != 0;
     else if (!strcmp(key, "timing"))
         h->kn_timing = atoi(value) != 0;
+    else if (!strcmp(key, "var_small"))
+        h->kn_var_small = atoi(value) != 0;
     else if (!strcmp(key, "occ"))
         h->kn_occ = std::max(1, std::min(4, atoi(value)));
     else
