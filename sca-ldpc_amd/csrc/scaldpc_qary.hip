@@ -751,7 +751,7 @@ __global__ void k_q_var(int v0, const int *__restrict__ col_ptr, const int *__re
     }
 }
 
-// The same update with everything in registers, for the plain decoder with a small alphabet (Q = 3, 5) and columns of at
+// The same update with everything in registers, for the plain decoder with alphabets Q = 3, 5, 7, 15 and columns of at
 // most DMAX checks: every incoming message is loaded ONCE (the generic kernel reads each twice, with an LDS round trip
 // between global accesses), all of a column's loads are issued before the first add.  Same additions and subtractions in
 // the same order, the same first-minimum rule: identical symbols.  llr is [var][Q][Bp] here (one alphabet).
@@ -849,7 +849,7 @@ struct scaldpc_qary {
     int kn_tree = 1;     // special decoder: tree-walk check kernel for the Kyber shape (QB = 5, 6 coefficient edges)
     // measurement aid (bench.py): with "timing" = 1 every check / variable launch of a call is bracketed by HIP events
     // on the launch stream; scaldpc_qary_last_timing reads the sums.  Off by default: the product path records nothing.
-    int kn_var_small = 1;  // register-resident variable update for Q = 3 / 5 and columns of at most 4 checks (A/B knob "var_small")
+    int kn_var_small = 1;  // register-resident variable update for Q = 3 / 5 / 7 / 15 and columns of at most 4 checks (A/B knob "var_small")
     int kn_occ = 2;      // unrolled enumeration: waves per SIMD the kernel is compiled for (1 .. 4; A/B knob "occ")
     int kn_timing = 0;
     std::vector<hipEvent_t> tev;
@@ -1117,10 +1117,15 @@ int qary_run(scaldpc_qary *h, const float *pmf_b, const float *pmf_s, int batch,
 #define QVAR_SMALL(QQ)                                                                                              \
     hipLaunchKernelGGL((k_q_var_small<QQ, 4>), dim3(h->N, Bp / 64), dim3(64), 0, s, h->d_col_ptr, h->d_csc_edge, h->d_edge_h, \
                        h->d_llr, h->d_msg, Bp, batch, it == iters ? 1 : 0, h->d_hard)
-        if (!h->special && h->kn_var_small && h->maxdv <= 4 && h->Q == 3)
+        const bool vs = !h->special && h->kn_var_small && h->maxdv <= 4;
+        if (vs && h->Q == 3)
             QVAR_SMALL(3);
-        else if (!h->special && h->kn_var_small && h->maxdv <= 4 && h->Q == 5)
+        else if (vs && h->Q == 5)
             QVAR_SMALL(5);
+        else if (vs && h->Q == 7)
+            QVAR_SMALL(7);
+        else if (vs && h->Q == 15)  // (B = 7: the reference's criterion and unit-test decoders)
+            QVAR_SMALL(15);
         else
             hipLaunchKernelGGL(k_q_var, dim3(h->N, Bp / TB), dim3(TB), (size_t)2 * h->W * TB * 4, s, 0, h->d_col_ptr,
                                h->d_csc_edge, h->d_edge_h, h->d_var_q, h->d_var_off, h->d_llr, h->d_msg, h->W, Bp, batch, h->W,
