@@ -427,12 +427,13 @@ __global__ __launch_bounds__(64) void k_q_check_wave(const int *__restrict__ row
         // digits of this lane's first assignment and of the stride 64, index 0 fastest
         u64 idx = 0, stp = 0;
         {
-            unsigned long long a = (unsigned long long)lane, st = 64;
+            unsigned a = (unsigned)lane, st = 64;  // (both start below 65: 32-bit division, not the 64-bit library routine)
             for (int j = 0; j < k - 1; j++) {
-                idx |= (u64)(a % num[j]) << (8 * j);
-                a /= num[j];
-                stp |= (u64)(st % num[j]) << (8 * j);
-                st /= num[j];
+                const unsigned nj = num[j];
+                idx |= (u64)(a % nj) << (8 * j);
+                a /= nj;
+                stp |= (u64)(st % nj) << (8 * j);
+                st /= nj;
             }
         }
         int nconf = 0;
@@ -474,9 +475,21 @@ __global__ __launch_bounds__(64) void k_q_check_wave(const int *__restrict__ row
         const u64 any = __ballot(nconf > 0);
         if (!any && lane == 0) atomicMax(err, QERR_NO_CONFIG);
     }
-    for (int i = 0; i < k * Q; i++) {
-        const float v = wave_min(Bt[(size_t)i * 64 + lane]);
-        if (lane == 0) msg[((size_t)(e0 + i / Q) * Q + i % Q) * Bp + b] = v;
+    // minimum over the 64 lanes' partial results, TRANSPOSED: lane L folds whole rows i = L, L + 64, ... of Bt (64 LDS reads
+    // each, rotated by the lane index so that the 64 lanes hit 32 different banks) instead of 6 dependent ds_bpermute steps
+    // per entry (k * Q entries: 630 of them for a degree-7 check over Q = 15)
+    __syncthreads();
+    for (int i = lane; i < k * Q; i += 64) {
+        const float *row = Bt + (size_t)i * 64;
+        float m0 = INFINITY, m1 = INFINITY, m2 = INFINITY, m3 = INFINITY;
+#pragma unroll 4
+        for (int l = 0; l < 64; l += 4) {
+            m0 = vmin(m0, row[(l + lane) & 63]);
+            m1 = vmin(m1, row[(l + 1 + lane) & 63]);
+            m2 = vmin(m2, row[(l + 2 + lane) & 63]);
+            m3 = vmin(m3, row[(l + 3 + lane) & 63]);
+        }
+        msg[((size_t)(e0 + i / Q) * Q + i % Q) * Bp + b] = vmin(vmin(m0, m1), vmin(m2, m3));
     }
 }
 
