@@ -518,12 +518,13 @@ __global__ __launch_bounds__(64) void k_q_special_check_wave(const int *__restri
     for (int j = 0; j < nb; j++) total *= QB;
     u64 dq = 0, stp = 0;
     {
-        unsigned long long a = (unsigned long long)lane, st = 64;
+        unsigned a = (unsigned)lane, st = 64;  // (both start below 65: 32-bit division)
+        const unsigned uq = (unsigned)QB;
         for (int j = 0; j < nb; j++) {
-            dq |= (u64)(a % QB) << (8 * j);
-            a /= QB;
-            stp |= (u64)(st % QB) << (8 * j);
-            st /= QB;
+            dq |= (u64)(a % uq) << (8 * j);
+            a /= uq;
+            stp |= (u64)(st % uq) << (8 * j);
+            st /= uq;
         }
     }
     for (unsigned long long cfg = lane; cfg < total; cfg += 64) {
@@ -552,13 +553,23 @@ __global__ __launch_bounds__(64) void k_q_special_check_wave(const int *__restri
         }
         dq = ndq;
     }
-    for (int i = 0; i < nb * QB; i++) {
-        const float v = wave_min(Bb[(size_t)i * 64 + lane]);
-        if (lane == 0) msg[((size_t)(e0 + i / QB) * W + i % QB) * Bp + b] = v;
-    }
-    for (int i = 0; i < QS; i++) {
-        const float v = wave_min(Bs[(size_t)i * 64 + lane]);
-        if (lane == 0) msg[((size_t)(e0 + nb) * W + i) * Bp + b] = v;
+    // minima over the 64 lanes, transposed (see k_q_check_wave): the row's nb * QB coefficient entries, then its QS sum entries
+    __syncthreads();
+    for (int i = lane; i < nb * QB + QS; i += 64) {
+        const float *row = i < nb * QB ? Bb + (size_t)i * 64 : Bs + (size_t)(i - nb * QB) * 64;
+        float m0 = INFINITY, m1 = INFINITY, m2 = INFINITY, m3 = INFINITY;
+#pragma unroll 4
+        for (int l = 0; l < 64; l += 4) {
+            m0 = vmin(m0, row[(l + lane) & 63]);
+            m1 = vmin(m1, row[(l + 1 + lane) & 63]);
+            m2 = vmin(m2, row[(l + 2 + lane) & 63]);
+            m3 = vmin(m3, row[(l + 3 + lane) & 63]);
+        }
+        const float v = vmin(vmin(m0, m1), vmin(m2, m3));
+        if (i < nb * QB)
+            msg[((size_t)(e0 + i / QB) * W + i % QB) * Bp + b] = v;
+        else
+            msg[((size_t)(e0 + nb) * W + (i - nb * QB)) * Bp + b] = v;
     }
 }
 
