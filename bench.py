@@ -665,8 +665,8 @@ def qary_bench(args, S, rank, world, dist, backend, local, iters):
                 "peak": None, "frac": None, "traffic": None, "launches_per_call": launches,
                 "device_loop_ms": kt["ms_loop"], "call_ms": dt / args.steps * 1e3,
                 "what": "batch-1 latency of the reference's criterion case; no VALU / HBM fraction is claimed: the work is a few "
-                        "finite-support assignments per check, the time is launch and copy latency (see cpu_baseline: one host "
-                        "core finishes the same call sooner)",
+                        "finite-support assignments per check, the time is launch and copy latency (compare "
+                        "cpu_baseline.single_thread_ms_per_call: one host core runs the same call in 0.04 ms (6x3) / 0.37 ms (150x450))",
             }
         if per_rank_ms:
             line["per_rank_ms_per_step"] = per_rank_ms
