@@ -90,6 +90,52 @@ __global__ void k_q_into_llr(const float *__restrict__ pmf, int nv, int Q, int b
     for (int q = 0; q < Q; q++) llr[((size_t)v * Q + q) * Bp + b] = glibc_logf(mx / p[q]);
 }
 
+// The same conversion through an LDS tile: the input is [codeword][variable][Q] (a codeword's pmf rows are contiguous), the
+// output [variable][Q][codeword] -- with thread = (variable, codeword) and lane = codeword every lane read its own 12-byte
+// row from a different cache line (28 us for config 4's 1024 x 450 x 3 floats).  Here a wave takes 64 codewords x VT
+// variables: it loads each codeword's VT * Q contiguous floats with neighbouring lanes (one or two sectors per row), then
+// lane = codeword reads its row from LDS (row stride 33: conflict free) and writes llr with 64 codewords per store.
+// Same arithmetic, same error key.  grid (ceil(nv / VT), Bp / 64), block 64, VT = max(1, 32 / Q).
+__global__ __launch_bounds__(64) void k_q_into_llr_tiled(const float *__restrict__ pmf, int nv, int Q, int VT, int batch, long Bp,
+                                                         float *__restrict__ llr, int *__restrict__ err,
+                                                         u64 *__restrict__ first_bad, int kind)
+{
+    __shared__ float tile[64 * 33];
+    const int lane = threadIdx.x;
+    const int v0 = blockIdx.x * VT;
+    const long b0 = (long)blockIdx.y * 64;
+    const int nvv = min(VT, nv - v0), width = nvv * Q;  // floats per codeword in this tile (<= 32)
+    if (lane < width) {
+#pragma unroll 8
+        for (int c = 0; c < 64; c++)
+            if (b0 + c < batch) tile[c * 33 + lane] = pmf[((size_t)(b0 + c) * nv + v0) * Q + lane];
+    }
+    __syncthreads();
+    const long b = b0 + lane;
+    for (int vv = 0; vv < nvv; vv++) {
+        const int v = v0 + vv;
+        if (b >= batch) {  // padding lanes decode a harmless all-equal message
+            for (int q = 0; q < Q; q++) llr[((size_t)v * Q + q) * Bp + b] = 0.0f;
+            continue;
+        }
+        const float *p = tile + lane * 33 + vv * Q;
+        float sum = 0.0f, mx = 0.0f;
+        bool have = false;
+        for (int q = 0; q < Q; q++) {
+            sum += p[q];
+            if (p[q] == p[q] && (!have || p[q] > mx)) {
+                mx = p[q];
+                have = true;
+            }
+        }
+        if (!have || !(sum < 1.0f + 0.001f) || !(sum > 1.0f - 0.001f)) {
+            atomicMax(err, QERR_PMF);
+            atomicMin(first_bad, ((u64)b << 32) | ((u64)kind << 31) | ((u64)v << 1) | (have ? 0ull : 1ull));
+        }
+        for (int q = 0; q < Q; q++) llr[((size_t)v * Q + q) * Bp + b] = glibc_logf(mx / p[q]);
+    }
+}
+
 // The same conversion on rows as they stand: pmf [rows][Q] -> llr [rows][Q] (scaldpc_qary_into_llr).
 // bad[0] = smallest row index that fails the sum test (or has no maximum), as k_q_into_llr's key.
 __global__ void k_q_into_llr_rows(const float *__restrict__ pmf, long rows, int Q, float *__restrict__ llr,
@@ -873,6 +919,7 @@ struct scaldpc_qary {
     int kn_tree = 1;     // special decoder: tree-walk check kernel for the Kyber shape (QB = 5, 6 coefficient edges)
     // measurement aid (bench.py): with "timing" = 1 every check / variable launch of a call is bracketed by HIP events
     // on the launch stream; scaldpc_qary_last_timing reads the sums.  Off by default: the product path records nothing.
+    int kn_llr_tiled = 1;  // probability -> LLR conversion through an LDS tile (coalesced reads); A/B knob "llr_tiled"
     int kn_var_small = 1;  // register-resident variable update for Q = 3 / 5 / 7 / 15 and columns of at most 4 checks (A/B knob "var_small")
     int kn_occ = 2;      // unrolled enumeration: waves per SIMD the kernel is compiled for (1 .. 4; A/B knob "occ")
     int kn_timing = 0;
@@ -1037,12 +1084,20 @@ int qary_run(scaldpc_qary *h, const float *pmf_b, const float *pmf_s, int batch,
             dp_s = h->d_pmf2;
         }
     }
-    hipLaunchKernelGGL(k_q_into_llr, dim3(BV, Bp / TB), dim3(TB), 0, s, dp_b, BV, h->Q, batch, Bp, h->d_llr, h->d_err,
-                       h->d_first_bad, 0);
+    // (alphabets of up to 32 symbols go through the LDS-tiled form: coalesced reads of [codeword][variable][Q])
+    auto into_llr = [&](const float *dp, int nv, int Q, float *llr, int kind) {
+        if (Q <= 32 && h->kn_llr_tiled) {
+            const int VT = std::max(1, 32 / Q);
+            hipLaunchKernelGGL(k_q_into_llr_tiled, dim3((nv + VT - 1) / VT, Bp / 64), dim3(64), 0, s, dp, nv, Q, VT, batch, Bp, llr,
+                               h->d_err, h->d_first_bad, kind);
+        } else
+            hipLaunchKernelGGL(k_q_into_llr, dim3(nv, Bp / TB), dim3(TB), 0, s, dp, nv, Q, batch, Bp, llr, h->d_err, h->d_first_bad,
+                               kind);
+    };
+    into_llr(dp_b, BV, h->Q, h->d_llr, 0);
     SC_HIP(hipGetLastError());
     if (h->special) {
-        hipLaunchKernelGGL(k_q_into_llr, dim3(h->R, Bp / TB), dim3(TB), 0, s, dp_s, h->R, h->QS, batch, Bp,
-                           h->d_llr + (size_t)BV * h->Q * Bp, h->d_err, h->d_first_bad, 1);
+        into_llr(dp_s, h->R, h->QS, h->d_llr + (size_t)BV * h->Q * Bp, 1);
         SC_HIP(hipGetLastError());
     }
     if (h->E) {
@@ -1270,6 +1325,8 @@ int scaldpc_qary_configure(scaldpc_qary *h, const char *key, const char *value)
         h->kn_tree = atoi(value) != 0;
     else if (!strcmp(key, "timing"))
         h->kn_timing = atoi(value) != 0;
+    else if (!strcmp(key, "llr_tiled"))
+        h->kn_llr_tiled = atoi(value) != 0;
     else if (!strcmp(key, "var_small"))
         h->kn_var_small = atoi(value) != 0;
     else if (!strcmp(key, "occ"))
