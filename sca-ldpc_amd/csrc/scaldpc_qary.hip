@@ -92,48 +92,45 @@ __global__ void k_q_into_llr(const float *__restrict__ pmf, int nv, int Q, int b
 
 // The same conversion through an LDS tile: the input is [codeword][variable][Q] (a codeword's pmf rows are contiguous), the
 // output [variable][Q][codeword] -- with thread = (variable, codeword) and lane = codeword every lane read its own 12-byte
-// row from a different cache line (28 us for config 4's 1024 x 450 x 3 floats).  Here a wave takes 64 codewords x VT
-// variables: it loads each codeword's VT * Q contiguous floats with neighbouring lanes (one or two sectors per row), then
-// lane = codeword reads its row from LDS (row stride 33: conflict free) and writes llr with 64 codewords per store.
-// Same arithmetic, same error key.  grid (ceil(nv / VT), Bp / 64), block 64, VT = max(1, 32 / Q).
-__global__ __launch_bounds__(64) void k_q_into_llr_tiled(const float *__restrict__ pmf, int nv, int Q, int VT, int batch, long Bp,
-                                                         float *__restrict__ llr, int *__restrict__ err,
-                                                         u64 *__restrict__ first_bad, int kind)
+// row from a different cache line (28 us for config 4's 1024 x 450 x 3 floats).  Here a workgroup takes 64 codewords x VT
+// variables, one wave per variable: the waves load each codeword's VT * Q contiguous floats with neighbouring lanes (one
+// or two sectors per row), then wave w, lane = codeword, converts variable w from LDS (row stride 33: conflict free) and
+// writes llr with 64 codewords per store.  Same arithmetic, same error key, as many waves as before.
+// grid (ceil(nv / VT), Bp / 64), block 64 * VT, VT = max(1, 32 / Q) (at most 10).
+__global__ void k_q_into_llr_tiled(const float *__restrict__ pmf, int nv, int Q, int VT, int batch, long Bp,
+                                   float *__restrict__ llr, int *__restrict__ err, u64 *__restrict__ first_bad, int kind)
 {
     __shared__ float tile[64 * 33];
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int v0 = blockIdx.x * VT;
     const long b0 = (long)blockIdx.y * 64;
     const int nvv = min(VT, nv - v0), width = nvv * Q;  // floats per codeword in this tile (<= 32)
-    if (lane < width) {
-#pragma unroll 8
-        for (int c = 0; c < 64; c++)
+    if (lane < width)
+        for (int c = w; c < 64; c += VT)
             if (b0 + c < batch) tile[c * 33 + lane] = pmf[((size_t)(b0 + c) * nv + v0) * Q + lane];
-    }
     __syncthreads();
+    if (w >= nvv) return;
+    const int v = v0 + w;
     const long b = b0 + lane;
-    for (int vv = 0; vv < nvv; vv++) {
-        const int v = v0 + vv;
-        if (b >= batch) {  // padding lanes decode a harmless all-equal message
-            for (int q = 0; q < Q; q++) llr[((size_t)v * Q + q) * Bp + b] = 0.0f;
-            continue;
-        }
-        const float *p = tile + lane * 33 + vv * Q;
-        float sum = 0.0f, mx = 0.0f;
-        bool have = false;
-        for (int q = 0; q < Q; q++) {
-            sum += p[q];
-            if (p[q] == p[q] && (!have || p[q] > mx)) {
-                mx = p[q];
-                have = true;
-            }
-        }
-        if (!have || !(sum < 1.0f + 0.001f) || !(sum > 1.0f - 0.001f)) {
-            atomicMax(err, QERR_PMF);
-            atomicMin(first_bad, ((u64)b << 32) | ((u64)kind << 31) | ((u64)v << 1) | (have ? 0ull : 1ull));
-        }
-        for (int q = 0; q < Q; q++) llr[((size_t)v * Q + q) * Bp + b] = glibc_logf(mx / p[q]);
+    if (b >= batch) {  // padding lanes decode a harmless all-equal message
+        for (int q = 0; q < Q; q++) llr[((size_t)v * Q + q) * Bp + b] = 0.0f;
+        return;
     }
+    const float *p = tile + lane * 33 + w * Q;
+    float sum = 0.0f, mx = 0.0f;
+    bool have = false;
+    for (int q = 0; q < Q; q++) {
+        sum += p[q];
+        if (p[q] == p[q] && (!have || p[q] > mx)) {
+            mx = p[q];
+            have = true;
+        }
+    }
+    if (!have || !(sum < 1.0f + 0.001f) || !(sum > 1.0f - 0.001f)) {
+        atomicMax(err, QERR_PMF);
+        atomicMin(first_bad, ((u64)b << 32) | ((u64)kind << 31) | ((u64)v << 1) | (have ? 0ull : 1ull));
+    }
+    for (int q = 0; q < Q; q++) llr[((size_t)v * Q + q) * Bp + b] = glibc_logf(mx / p[q]);
 }
 
 // The same conversion on rows as they stand: pmf [rows][Q] -> llr [rows][Q] (scaldpc_qary_into_llr).
@@ -1088,8 +1085,8 @@ int qary_run(scaldpc_qary *h, const float *pmf_b, const float *pmf_s, int batch,
     auto into_llr = [&](const float *dp, int nv, int Q, float *llr, int kind) {
         if (Q <= 32 && h->kn_llr_tiled) {
             const int VT = std::max(1, 32 / Q);
-            hipLaunchKernelGGL(k_q_into_llr_tiled, dim3((nv + VT - 1) / VT, Bp / 64), dim3(64), 0, s, dp, nv, Q, VT, batch, Bp, llr,
-                               h->d_err, h->d_first_bad, kind);
+            hipLaunchKernelGGL(k_q_into_llr_tiled, dim3((nv + VT - 1) / VT, Bp / 64), dim3(64 * VT), 0, s, dp, nv, Q, VT, batch, Bp,
+                               llr, h->d_err, h->d_first_bad, kind);
         } else
             hipLaunchKernelGGL(k_q_into_llr, dim3(nv, Bp / TB), dim3(TB), 0, s, dp, nv, Q, batch, Bp, llr, h->d_err, h->d_first_bad,
                                kind);
