@@ -49,7 +49,7 @@ namespace {
 
 struct HostBuckets {
     Buckets bk;
-    std::vector<int> list;
+    pvec<int> list;
     bool has_generic = false;
 };
 
@@ -117,7 +117,7 @@ struct scaldpc_bp {
     size_t cap_h_io = 0, cap_out_all = 0;
     bool small_prepared = false;  // k_small_prepare already reset the state this call (run_core / the early-exit loop skip theirs)
     // Monte-Carlo helpers
-    std::vector<double> h_probs;
+    pvec<double> h_probs;
     u64 *d_thr = nullptr, *d_mc = nullptr, *d_diff = nullptr;
     int *d_ylist = nullptr;
     uint8_t *d_succ = nullptr;
@@ -146,21 +146,21 @@ struct scaldpc_bp {
     int el_waves = 0;     // bins in use
     int el_cap_bins = 0;  // bins d_el_tab has room for
     bool el_ok = false;   // the row-parallel path can take this graph (non-empty, no row / column wider than a wave)
-    std::vector<int> h_el_slots, h_el_col;  // host mirrors of the two parts of d_el_tab
-    std::vector<int> seg_slot;            // per column: bin * 64 + first lane of its segment (-1: none)
-    std::vector<unsigned char> seg_cap;   // per column: lanes of its segment
+    pvec<int> h_el_slots, h_el_col;  // host mirrors of the two parts of d_el_tab
+    pvec<int> seg_slot;            // per column: bin * 64 + first lane of its segment (-1: none)
+    pvec<unsigned char> seg_cap;   // per column: lanes of its segment
     int el_open_used = 0;                 // lanes handed out in the last bin
     // A handle whose graph grows (scaldpc_bp_append_rows): CSR and priors move to allocations of their
     // own with spare capacity, the row-parallel tables keep a few free lanes per column and are
     // updated in place; everything only the tile / LDS kernels need (CSC, degree buckets, their
     // tables) is marked stale and rebuilt from the host mirror when one of those paths is next taken.
     bool incremental = false, full_stale = false;
-    std::vector<int> hg_col_idx;  // host CSR mirror (incremental handles)
+    pvec<int> hg_col_idx;  // host CSR mirror (incremental handles)
     int *d_csr_rp = nullptr, *d_csr_ci = nullptr;
     float *d_prior_buf = nullptr;
     size_t cap_rows = 0, cap_edges = 0, cap_cols = 0;
     int ws_m = 0, ws_n = 0;  // what the workspace planes are sized for
-    std::vector<int> el_dirty_slot, el_dirty_col;  // words an append call changed (kept for their capacity)
+    pvec<int> el_dirty_slot, el_dirty_col;  // words an append call changed (kept for their capacity)
     int *d_pairs = nullptr;  // staging of table updates
     int *h_pairs = nullptr;  // pinned
     size_t cap_pairs = 0;
@@ -177,7 +177,7 @@ struct scaldpc_bp {
     int first_method = -1;
     float first_alpha = 0.0f;
     int *d_el_tab = nullptr;    // k_el_var slots and wave info (d_el_slots, d_el_winfo)
-    std::vector<int> hg_row_ptr, hg_cdeg, hg_col_ptr, hg_csc_edge;
+    pvec<int> hg_row_ptr, hg_cdeg, hg_col_ptr, hg_csc_edge;
     HostBuckets hg_var, hg_row;
     int stat_el = 0;  // codewords the row-parallel kernels decoded in the last call
     int identity_from = -1;  // n - m if the last m columns of H are I_m (H = [Hin | I]), else -1
@@ -244,7 +244,7 @@ void knobs_from_env(Knobs &k)
 }
 
 // bucket b holds nodes with bounds[b-1] < deg <= bounds[b]; beyond the last bound -> generic (maxd 0)
-void build_buckets(const std::vector<int> &deg, const int *bounds, int nb, bool keep_isolated, HostBuckets &out)
+void build_buckets(const pvec<int> &deg, const int *bounds, int nb, bool keep_isolated, HostBuckets &out)
 {
     // Stable counting sort by degree (ascending node id inside a degree): bucket lists are
     // degree ranges of it, so neighbouring waves of a launch run the same exact-degree code
@@ -253,10 +253,10 @@ void build_buckets(const std::vector<int> &deg, const int *bounds, int nb, bool 
     const int n = (int)deg.size();
     int maxdeg = 0;
     for (int d : deg) maxdeg = std::max(maxdeg, d);
-    std::vector<int> start(maxdeg + 2, 0);
+    pvec<int> start(maxdeg + 2, 0);
     for (int d : deg) start[d + 1]++;
     for (int d = 0; d <= maxdeg; d++) start[d + 1] += start[d];
-    std::vector<int> order(n), cursor(start.begin(), start.end() - 1);
+    pvec<int> order(n), cursor(start.begin(), start.end() - 1);
     for (int i = 0; i < n; i++) order[cursor[deg[i]]++] = i;
     out.list.clear();
     out.list.reserve(n);
@@ -423,7 +423,7 @@ int ensure_tile_tables(scaldpc_bp *h)
     // degree.  var_order = 1 re-sorts each run of equal degree by the column's FIRST edge id, so that
     // neighbouring waves of a launch start their gathers in neighbouring rows of the message array
     // (the records carry the column id, so the order is free; results cannot depend on it).
-    std::vector<int> order_buf;
+    pvec<int> order_buf;
     const int *vlist = hv.list.data();
     // auto: a tile group that runs as ONE stream lane (a tile too large to share the cache with a second one:
     // the HQC-256 graph) has nothing to fill the tail of its launches with, so its heaviest columns go first
@@ -1204,7 +1204,7 @@ int decode_level(scaldpc_bp *h, int lvl, const TileState &st, int batch, int T, 
     std::vector<u64> done_h(T);
     SC_HIP(hipMemcpyAsync(done_h.data(), st.done, sizeof(u64) * T, hipMemcpyDeviceToHost, s));
     SC_HIP(hipStreamSynchronize(s));
-    std::vector<int> ids, slot_of((size_t)T * TW, -1);
+    pvec<int> ids, slot_of((size_t)T * TW, -1);
     for (int t = 0; t < T; t++) {
         if (!deferred_tile[t]) continue;
         for (int c = 0; c < TW; c++) {
@@ -1325,7 +1325,7 @@ namespace {
 // (ensure_tile_tables / ensure_el_tables).  Used by scaldpc_bp_create and, on a handle whose graph
 // has grown, by refresh_full (there CSR and priors already live in buffers of their own).
 // Consumes cdeg.
-int finish_graph(scaldpc_bp *h, const int *row_ptr, const int *col_idx, const std::vector<int> &rdeg, std::vector<int> &cdeg)
+int finish_graph(scaldpc_bp *h, const int *row_ptr, const int *col_idx, const pvec<int> &rdeg, pvec<int> &cdeg)
 {
     const int m = h->m, n = h->n;
     const long nnz = h->E;
@@ -1373,7 +1373,7 @@ int finish_graph(scaldpc_bp *h, const int *row_ptr, const int *col_idx, const st
     {
         col_ptr[0] = 0;
         for (int j = 0; j < n; j++) col_ptr[j + 1] = col_ptr[j] + cdeg[j];
-        std::vector<int> cursor(col_ptr, col_ptr + n);
+        pvec<int> cursor(col_ptr, col_ptr + n);
         for (int e = 0; e < (int)nnz; e++) csc_edge[cursor[col_idx[e]]++] = e;
     }
     std::copy(hv.list.begin(), hv.list.end(), host + o_var_list);
@@ -1455,7 +1455,7 @@ int grow_keep(T **p, size_t *cap, size_t used, size_t need)
 int refresh_full(scaldpc_bp *h)
 {
     if (!h->full_stale) return 0;
-    std::vector<int> rdeg(h->m), cdeg(h->hg_cdeg);
+    pvec<int> rdeg(h->m), cdeg(h->hg_cdeg);
     for (int r = 0; r < h->m; r++) rdeg[r] = h->hg_row_ptr[r + 1] - h->hg_row_ptr[r];
     dev_free(h->d_graph);
     dev_free(h->d_tile_tab);
@@ -1483,7 +1483,7 @@ int scaldpc_bp_create(int32_t m, int32_t n, int64_t nnz, const int32_t *row_ptr,
     if (nnz > 0x7fffffffLL) return fail(SCALDPC_EINVAL, "nnz too large");
     if (row_ptr[0] != 0 || row_ptr[m] != nnz) return fail(SCALDPC_EINVAL, "row_ptr does not span [0, nnz]");
     TMARK("start");
-    std::vector<int> rdeg(m), cdeg(n, 0);
+    pvec<int> rdeg(m), cdeg(n, 0);
     for (int r = 0; r < m; r++) {
         if (row_ptr[r + 1] < row_ptr[r]) return fail(SCALDPC_EINVAL, "row_ptr not monotone at row %d", r);
         rdeg[r] = row_ptr[r + 1] - row_ptr[r];
@@ -1518,7 +1518,7 @@ int scaldpc_bp_set_channel_probs(scaldpc_bp *h, const double *probs)
     std::lock_guard<std::mutex> lk(h->mu);
     if (h->broken) return fail(SCALDPC_EHIP, "this decoder is unusable: an earlier scaldpc_bp_append_rows failed part-way; destroy it and build a new one");
     DeviceGuard dg(h->device);
-    std::vector<float> llr(h->n);
+    pvec<float> llr(h->n);
     float last_p = 0.0f, last_llr = 0.0f;
     for (int j = 0; j < h->n; j++) {
         if (!(probs[j] >= 0.0 && probs[j] <= 1.0))
@@ -1553,7 +1553,7 @@ int scaldpc_bp_set_channel_probs_tail(scaldpc_bp *h, int32_t first, int32_t coun
     if (first > h->prior_n) return fail(SCALDPC_EINVAL, "priors of columns [%d, %d) are still unset", h->prior_n, first);
     if (count == 0) return 0;
     if (h->async_used) SC_HIP(hipDeviceSynchronize());
-    std::vector<float> llr(count);
+    pvec<float> llr(count);
     float last_p = 0.0f, last_llr = 0.0f;
     for (int j = 0; j < count; j++) {
         if (!(probs[j] >= 0.0 && probs[j] <= 1.0))
@@ -1627,7 +1627,7 @@ int scaldpc_bp_append_rows(scaldpc_bp *h, int32_t nrows, const int32_t *row_ptr,
     TMARK("app:mirror");
     // ---- row-parallel tables, in place: one slot word per new edge while its column has a free lane
     const bool had_tables = h->d_el_tab != nullptr;
-    std::vector<int> &dirty_slot = h->el_dirty_slot, &dirty_col = h->el_dirty_col;  // words of h_el_slots / h_el_col that changed
+    pvec<int> &dirty_slot = h->el_dirty_slot, &dirty_col = h->el_dirty_col;  // words of h_el_slots / h_el_col that changed
     dirty_slot.clear();
     dirty_col.clear();
     bool el_alive = had_tables;
@@ -2073,7 +2073,7 @@ int scaldpc_mc_fer_run(scaldpc_bp *h, int64_t first_trial, int32_t batch, uint64
     SC_TRY(grow(&h->d_mc, &h->cap_mc, (size_t)T * h->n));
     if (!h->thr_valid) {
         if (!h->d_thr) SC_TRY(dev_alloc(&h->d_thr, (size_t)h->n));
-        std::vector<u64> thr(h->n);
+        pvec<u64> thr(h->n);
         for (int j = 0; j < h->n; j++) thr[j] = bernoulli_threshold(h->h_probs[j]);
         SC_HIP(hipMemcpy(h->d_thr, thr.data(), sizeof(u64) * h->n, hipMemcpyHostToDevice));
         h->thr_valid = true;

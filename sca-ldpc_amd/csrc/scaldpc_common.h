@@ -5,6 +5,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <string>
+#include <vector>
 
 #include "../../include/scaldpc.h"
 
@@ -65,6 +66,31 @@ struct DeviceGuard {
 // Streams of destroyed handles are parked per device and handed to the next handle created there.
 int stream_acquire(hipStream_t *out, int *device);
 void stream_release(hipStream_t s, int device);
+
+// Host memory for a handle's graph mirrors and tables, through a small per-process pool of released blocks.  The
+// reference builds a NEW decoder for every decode (hqc.py:694), i.e. a few multi-megabyte std::vectors are allocated and
+// freed per decode; glibc hands such sizes to mmap / trims the heap top on free, so the next decoder page-faults every
+// byte again -- and depending on what else the process (Python, NumPy) has on the heap this flips between 0.45 ms and
+// 2-8 ms per construction plus 1.5 ms per destroy (measured: profiles/r03/rebuild_probe.log).  Blocks of at least 32 KiB
+// are parked on release (at most 256 MiB in total; scaldpc_trim() returns them); smaller requests go to operator new.
+void *host_pool_alloc(size_t bytes);
+void host_pool_free(void *p, size_t bytes) noexcept;
+
+template <typename T>
+struct PoolAlloc {
+    using value_type = T;
+    PoolAlloc() noexcept = default;
+    template <typename U>
+    PoolAlloc(const PoolAlloc<U> &) noexcept {}
+    T *allocate(size_t n) { return static_cast<T *>(host_pool_alloc(n * sizeof(T))); }
+    void deallocate(T *p, size_t n) noexcept { host_pool_free(p, n * sizeof(T)); }
+    template <typename U>
+    bool operator==(const PoolAlloc<U> &) const noexcept { return true; }
+    template <typename U>
+    bool operator!=(const PoolAlloc<U> &) const noexcept { return false; }
+};
+template <typename T>
+using pvec = std::vector<T, PoolAlloc<T>>;
 
 template <typename T>
 inline int dev_alloc(T **p, size_t count)

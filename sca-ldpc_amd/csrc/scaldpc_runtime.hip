@@ -146,6 +146,67 @@ void cached_free(void *p)
     raw_free(p, b);
 }
 
+// ---- host pool behind PoolAlloc (see scaldpc_common.h) -----------------------------------------------------
+namespace {
+struct HostPool {
+    std::mutex mu;
+    std::vector<std::pair<void *, size_t>> idle;  // released blocks: pointer, capacity
+    size_t idle_bytes = 0;
+};
+HostPool &host_pool()
+{
+    static HostPool *p = new HostPool();  // never destroyed (static destruction order)
+    return *p;
+}
+constexpr size_t HOST_POOL_MIN = (size_t)32 << 10, HOST_POOL_TOTAL_MAX = (size_t)256 << 20, HOST_HDR = 64;
+}  // namespace
+
+// Every pooled block carries its capacity in a 64-byte header in front of the user pointer.
+void *host_pool_alloc(size_t bytes)
+{
+    if (bytes < HOST_POOL_MIN) return ::operator new(bytes);
+    HostPool &hp = host_pool();
+    {
+        std::lock_guard<std::mutex> lk(hp.mu);
+        size_t best = hp.idle.size();
+        for (size_t i = 0; i < hp.idle.size(); i++)  // smallest block that fits without wasting more than half
+            if (hp.idle[i].second >= bytes && hp.idle[i].second <= 2 * bytes + 4096 &&
+                (best == hp.idle.size() || hp.idle[i].second < hp.idle[best].second))
+                best = i;
+        if (best != hp.idle.size()) {
+            void *p = hp.idle[best].first;
+            hp.idle_bytes -= hp.idle[best].second;
+            hp.idle.erase(hp.idle.begin() + best);
+            return p;
+        }
+    }
+    const size_t cap = bytes + bytes / 8;  // a little headroom: the next decoder of a growing graph fits the same block
+    char *raw = static_cast<char *>(::operator new(cap + HOST_HDR));
+    *reinterpret_cast<size_t *>(raw) = cap;
+    return raw + HOST_HDR;
+}
+
+void host_pool_free(void *p, size_t bytes) noexcept
+{
+    if (!p) return;
+    if (bytes < HOST_POOL_MIN) {
+        ::operator delete(p);
+        return;
+    }
+    char *raw = static_cast<char *>(p) - HOST_HDR;
+    const size_t cap = *reinterpret_cast<size_t *>(raw);
+    HostPool &hp = host_pool();
+    {
+        std::lock_guard<std::mutex> lk(hp.mu);
+        if (hp.idle_bytes + cap <= HOST_POOL_TOTAL_MAX) {
+            hp.idle.emplace_back(p, cap);
+            hp.idle_bytes += cap;
+            return;
+        }
+    }
+    ::operator delete(raw);
+}
+
 // Streams of destroyed handles are parked per device and handed to the next handle created
 // there (creating and destroying a stream per decoder costs more than a single decode).
 struct StreamPool {
@@ -198,6 +259,14 @@ extern "C" int scaldpc_trim(void)
         bc.idle_bytes = 0;
     }
     for (auto &d : drop) raw_free(d.first, d.second);
+    std::vector<std::pair<void *, size_t>> hdrop;
+    {
+        HostPool &hp = host_pool();
+        std::lock_guard<std::mutex> lk(hp.mu);
+        hdrop.swap(hp.idle);
+        hp.idle_bytes = 0;
+    }
+    for (auto &d : hdrop) ::operator delete(static_cast<char *>(d.first) - HOST_HDR);
     return 0;
 }
 
