@@ -97,8 +97,14 @@ __global__ void k_q_into_llr(const float *__restrict__ pmf, int nv, int Q, int b
 // or two sectors per row), then wave w, lane = codeword, converts variable w from LDS (row stride 33: conflict free) and
 // writes llr with 64 codewords per store.  Same arithmetic, same error key, as many waves as before.
 // grid (ceil(nv / VT), Bp / 64), block 64 * VT, VT = max(1, 32 / Q) (at most 10).
+// With col_ptr != nullptr the wave also writes the variable's first variable-to-check messages (decoder.rs:567-573:
+// v2c = channel * h, i.e. the LLR row, mirrored where h < 0) to every edge of its variable -- k_q_init's job, without the
+// launch and without reading the LLRs back (vbase = index of this alphabet's first variable in the graph, W = message row width).
 __global__ void k_q_into_llr_tiled(const float *__restrict__ pmf, int nv, int Q, int VT, int batch, long Bp,
-                                   float *__restrict__ llr, int *__restrict__ err, u64 *__restrict__ first_bad, int kind)
+                                   float *__restrict__ llr, int *__restrict__ err, u64 *__restrict__ first_bad, int kind,
+                                   const int *__restrict__ col_ptr = nullptr, const int *__restrict__ csc_edge = nullptr,
+                                   const int *__restrict__ edge_h = nullptr, float *__restrict__ msg = nullptr, int W = 0,
+                                   int vbase = 0)
 {
     __shared__ float tile[64 * 33];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -112,8 +118,11 @@ __global__ void k_q_into_llr_tiled(const float *__restrict__ pmf, int nv, int Q,
     if (w >= nvv) return;
     const int v = v0 + w;
     const long b = b0 + lane;
+    const int c0 = col_ptr ? col_ptr[vbase + v] : 0, c1 = col_ptr ? col_ptr[vbase + v + 1] : 0;
     if (b >= batch) {  // padding lanes decode a harmless all-equal message
         for (int q = 0; q < Q; q++) llr[((size_t)v * Q + q) * Bp + b] = 0.0f;
+        for (int t = c0; t < c1; t++)
+            for (int q = 0; q < Q; q++) msg[((size_t)csc_edge[t] * W + q) * Bp + b] = 0.0f;
         return;
     }
     const float *p = tile + lane * 33 + w * Q;
@@ -130,7 +139,17 @@ __global__ void k_q_into_llr_tiled(const float *__restrict__ pmf, int nv, int Q,
         atomicMax(err, QERR_PMF);
         atomicMin(first_bad, ((u64)b << 32) | ((u64)kind << 31) | ((u64)v << 1) | (have ? 0ull : 1ull));
     }
-    for (int q = 0; q < Q; q++) llr[((size_t)v * Q + q) * Bp + b] = glibc_logf(mx / p[q]);
+    float *own = tile + lane * 33 + w * Q;  // (this thread's slots of the tile: probabilities in, LLRs out)
+    for (int q = 0; q < Q; q++) {
+        const float l = glibc_logf(mx / p[q]);
+        llr[((size_t)v * Q + q) * Bp + b] = l;
+        own[q] = l;
+    }
+    for (int t = c0; t < c1; t++) {
+        const int e = csc_edge[t];
+        const bool rev = edge_h[e] < 0;
+        for (int q = 0; q < Q; q++) msg[((size_t)e * W + q) * Bp + b] = own[rev ? Q - 1 - q : q];
+    }
 }
 
 // The same conversion on rows as they stand: pmf [rows][Q] -> llr [rows][Q] (scaldpc_qary_into_llr).
@@ -1082,11 +1101,18 @@ int qary_run(scaldpc_qary *h, const float *pmf_b, const float *pmf_s, int batch,
         }
     }
     // (alphabets of up to 32 symbols go through the LDS-tiled form: coalesced reads of [codeword][variable][Q])
+    // the tiled conversion also writes the first variable-to-check messages (k_q_init's job) when every alphabet takes it
+    const bool fused_init = h->kn_llr_tiled && h->Q <= 32 && (!h->special || h->QS <= 32) && h->E > 0;
     auto into_llr = [&](const float *dp, int nv, int Q, float *llr, int kind) {
         if (Q <= 32 && h->kn_llr_tiled) {
             const int VT = std::max(1, 32 / Q);
-            hipLaunchKernelGGL(k_q_into_llr_tiled, dim3((nv + VT - 1) / VT, Bp / 64), dim3(64 * VT), 0, s, dp, nv, Q, VT, batch, Bp,
-                               llr, h->d_err, h->d_first_bad, kind);
+            if (fused_init)
+                hipLaunchKernelGGL(k_q_into_llr_tiled, dim3((nv + VT - 1) / VT, Bp / 64), dim3(64 * VT), 0, s, dp, nv, Q, VT, batch,
+                                   Bp, llr, h->d_err, h->d_first_bad, kind, (const int *)h->d_col_ptr, (const int *)h->d_csc_edge,
+                                   (const int *)h->d_edge_h, h->d_msg, h->W, kind ? BV : 0);
+            else
+                hipLaunchKernelGGL(k_q_into_llr_tiled, dim3((nv + VT - 1) / VT, Bp / 64), dim3(64 * VT), 0, s, dp, nv, Q, VT, batch,
+                                   Bp, llr, h->d_err, h->d_first_bad, kind);
         } else
             hipLaunchKernelGGL(k_q_into_llr, dim3(nv, Bp / TB), dim3(TB), 0, s, dp, nv, Q, batch, Bp, llr, h->d_err, h->d_first_bad,
                                kind);
@@ -1097,7 +1123,7 @@ int qary_run(scaldpc_qary *h, const float *pmf_b, const float *pmf_s, int batch,
         into_llr(dp_s, h->R, h->QS, h->d_llr + (size_t)BV * h->Q * Bp, 1);
         SC_HIP(hipGetLastError());
     }
-    if (h->E) {
+    if (h->E && !fused_init) {
         hipLaunchKernelGGL(k_q_init, dim3(h->E, Bp / TB), dim3(TB), 0, s, h->d_edge_var, h->d_edge_h, h->d_var_q,
                            h->d_var_off, h->d_llr, h->d_msg, h->W, Bp);
         SC_HIP(hipGetLastError());
