@@ -842,20 +842,18 @@ __global__ void k_q_var(int v0, const int *__restrict__ col_ptr, const int *__re
 // between global accesses), all of a column's loads are issued before the first add.  Same additions and subtractions in
 // the same order, the same first-minimum rule: identical symbols.  llr is [var][Q][Bp] here (one alphabet).
 // grid (N, Bp/64), block 64.
+//   v: variable (graph index: column of col_ptr, row of `out`);  llr: this variable's Q rows;  W: width of a message row
 template <int Q, int DMAX>
-__global__ __launch_bounds__(64) void k_q_var_small(const int *__restrict__ col_ptr, const int *__restrict__ csc_edge,
-                                                    const int *__restrict__ edge_h, const float *__restrict__ llr, float *msg,
-                                                    long Bp, int batch, int last, signed char *__restrict__ out)
+__device__ __forceinline__ void var_small_body(int v, const float *__restrict__ llr, const int *__restrict__ col_ptr,
+                                               const int *__restrict__ csc_edge, const int *__restrict__ edge_h, float *msg, int W,
+                                               long Bp, long b, int last, signed char *__restrict__ out)
 {
-    const int v = blockIdx.x;
-    const long b = (long)blockIdx.y * 64 + threadIdx.x;
-    if (b >= batch) return;
     const int c0 = col_ptr[v], deg = col_ptr[v + 1] - c0;
     float sum[Q], in[DMAX][Q];
     int ed[DMAX];
     bool rv[DMAX];
 #pragma unroll
-    for (int q = 0; q < Q; q++) sum[q] = llr[((size_t)v * Q + q) * Bp + b];
+    for (int q = 0; q < Q; q++) sum[q] = llr[(size_t)q * Bp + b];
 #pragma unroll
     for (int t = 0; t < DMAX; t++) {
         ed[t] = 0;
@@ -864,7 +862,7 @@ __global__ __launch_bounds__(64) void k_q_var_small(const int *__restrict__ col_
             ed[t] = csc_edge[c0 + t];
             rv[t] = edge_h[ed[t]] < 0;
 #pragma unroll
-            for (int q = 0; q < Q; q++) in[t][q] = msg[((size_t)ed[t] * Q + q) * Bp + b];
+            for (int q = 0; q < Q; q++) in[t][q] = msg[((size_t)ed[t] * W + q) * Bp + b];
         }
     }
 #pragma unroll
@@ -887,7 +885,7 @@ __global__ __launch_bounds__(64) void k_q_var_small(const int *__restrict__ col_
                     mn = tmp[q];
                 }
 #pragma unroll
-            for (int q = 0; q < Q; q++) msg[((size_t)ed[t] * Q + q) * Bp + b] = tmp[q] - mn;
+            for (int q = 0; q < Q; q++) msg[((size_t)ed[t] * W + q) * Bp + b] = tmp[q] - mn;
         }
     if (last) {
         float mv = INFINITY;
@@ -900,6 +898,35 @@ __global__ __launch_bounds__(64) void k_q_var_small(const int *__restrict__ col_
             }
         out[(size_t)v * Bp + b] = (signed char)(ma - (Q - 1) / 2);
     }
+}
+
+template <int Q, int DMAX>
+__global__ __launch_bounds__(64) void k_q_var_small(const int *__restrict__ col_ptr, const int *__restrict__ csc_edge,
+                                                    const int *__restrict__ edge_h, const float *__restrict__ llr, float *msg,
+                                                    long Bp, int batch, int last, signed char *__restrict__ out)
+{
+    const int v = blockIdx.x;
+    const long b = (long)blockIdx.y * 64 + threadIdx.x;
+    if (b >= batch) return;
+    var_small_body<Q, DMAX>(v, llr + (size_t)v * Q * Bp, col_ptr, csc_edge, edge_h, msg, Q, Bp, b, last, out);
+}
+
+// DecoderSpecial (decoder_special.rs:566-609): the first BV variables over QA symbols (columns of at most DA checks), the
+// row-sum variables behind them over QS symbols, one check each; message rows are W = max(QA, QS) wide.
+// grid (N, Bp/64), block 64.
+template <int QA, int DA, int QS>
+__global__ __launch_bounds__(64) void k_q_var_small_special(const int *__restrict__ col_ptr, const int *__restrict__ csc_edge,
+                                                            const int *__restrict__ edge_h, const float *__restrict__ llr,
+                                                            float *msg, int BV, int W, long Bp, int batch, int last,
+                                                            signed char *__restrict__ out)
+{
+    const int v = blockIdx.x;
+    const long b = (long)blockIdx.y * 64 + threadIdx.x;
+    if (b >= batch) return;
+    if (v < BV)
+        var_small_body<QA, DA>(v, llr + (size_t)v * QA * Bp, col_ptr, csc_edge, edge_h, msg, W, Bp, b, last, out);
+    else
+        var_small_body<QS, 1>(v, llr + ((size_t)BV * QA + (size_t)(v - BV) * QS) * Bp, col_ptr, csc_edge, edge_h, msg, W, Bp, b, last, out);
 }
 
 // [N][Bp] -> [batch][N]
@@ -1228,6 +1255,9 @@ int qary_run(scaldpc_qary *h, const float *pmf_b, const float *pmf_s, int batch,
             QVAR_SMALL(7);
         else if (vs && h->Q == 15)  // (B = 7: the reference's criterion and unit-test decoders)
             QVAR_SMALL(15);
+        else if (h->special && h->kn_var_small && h->Q == 5 && h->QS == 25 && h->maxdv <= 4)  // the Kyber SW6 classes (lib.rs:54-75)
+            hipLaunchKernelGGL((k_q_var_small_special<5, 4, 25>), dim3(h->N, Bp / 64), dim3(64), 0, s, h->d_col_ptr, h->d_csc_edge,
+                               h->d_edge_h, h->d_llr, h->d_msg, BV, h->W, Bp, batch, it == iters ? 1 : 0, h->d_hard);
         else
             hipLaunchKernelGGL(k_q_var, dim3(h->N, Bp / TB), dim3(TB), (size_t)2 * h->W * TB * 4, s, 0, h->d_col_ptr,
                                h->d_csc_edge, h->d_edge_h, h->d_var_q, h->d_var_off, h->d_llr, h->d_msg, h->W, Bp, batch, h->W,
