@@ -86,7 +86,10 @@ int scaldpc_set_device(int device);
  * handles are parked for the next handle instead of going through hipFree: the reference builds
  * a new decoder per decode (simulate/hqc.py:694), and allocation would otherwise cost several
  * times the decode.  scaldpc_trim() returns the parked blocks to the driver;
- * SCALDPC_NO_CACHE=1 in the environment disables parking. */
+ * SCALDPC_NO_CACHE=1 in the environment disables parking.  The host-side graph mirrors and tables of a handle
+ * (a few multi-megabyte vectors) are recycled the same way (blocks >= 32 KiB, at most 256 MiB parked, also returned
+ * by scaldpc_trim()): left to malloc they are unmapped and page-faulted in again per decoder, at a cost that depends
+ * on the state of the host process's heap (0.45 ms or 2-8 ms per construction, measured). */
 int scaldpc_trim(void);
 /* Leak accounting (tests, profiles/microbench/leak_check.py): blocks the library's allocator has handed
  * out and that a live handle still owns.  out[6] = { device blocks, device bytes, pinned-host blocks,
