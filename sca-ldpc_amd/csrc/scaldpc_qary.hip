@@ -964,7 +964,7 @@ struct scaldpc_qary {
     // on the launch stream; scaldpc_qary_last_timing reads the sums.  Off by default: the product path records nothing.
     int kn_llr_tiled = 1;  // probability -> LLR conversion through an LDS tile (coalesced reads); A/B knob "llr_tiled"
     int kn_var_small = 1;  // register-resident variable update for Q = 3 / 5 / 7 / 15 and columns of at most 4 checks (A/B knob "var_small")
-    int kn_occ = 2;      // unrolled enumeration: waves per SIMD the kernel is compiled for (1 .. 4; A/B knob "occ")
+    int kn_occ = 2;      // unrolled enumeration: waves per SIMD the kernel is compiled for (1 or 2; A/B knob "occ")
     int kn_timing = 0;
     std::vector<hipEvent_t> tev;
     float stat_ms_check = 0.f, stat_ms_var = 0.f, stat_ms_call = 0.f;
@@ -1069,7 +1069,7 @@ int qary_build(int R, int N, int B, int BSUM, bool special, const int8_t *H, int
     if (!rc && hipGetDevice(&h->device) != hipSuccess) rc = fail(SCALDPC_EHIP, "hipGetDevice failed");
     if (const char *e = getenv("SCALDPC_QARY_WAVE")) h->kn_wave = atoi(e) != 0;  // the environment is read once per handle
     if (getenv("SCALDPC_QARY_NO_UNROLL")) h->kn_unroll = 0;
-    if (const char *o = getenv("SCALDPC_QARY_OCC")) h->kn_occ = std::max(1, std::min(4, atoi(o)));
+    if (const char *o = getenv("SCALDPC_QARY_OCC")) h->kn_occ = atoi(o) <= 1 ? 1 : 2;
     if (getenv("SCALDPC_QARY_NO_TREE")) h->kn_tree = 0;
     if (!rc && hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking) != hipSuccess)
         rc = fail(SCALDPC_EHIP, "hipStreamCreate failed");
@@ -1201,20 +1201,10 @@ int qary_run(scaldpc_qary *h, const float *pmf_b, const float *pmf_s, int batch,
     hipLaunchKernelGGL((k_q_check_unrolled<QQ, KK, OCC>), dim3(h->R, Bp / 64), dim3(64), 0, s, h->d_row_ptr, h->d_msg, Bp, \
                        batch, h->d_err)
             if (unrolled == 3) {
-                switch (h->kn_occ) {
-                    case 1: QUNROLLED(3, 7, 1); break;
-                    case 3: QUNROLLED(3, 7, 3); break;
-                    case 4: QUNROLLED(3, 7, 4); break;
-                    default: QUNROLLED(3, 7, 2); break;
-                }
+                if (h->kn_occ == 1) QUNROLLED(3, 7, 1); else QUNROLLED(3, 7, 2);
             } else if (unrolled == 5) {
-                switch (h->kn_occ) {
-                    case 1: QUNROLLED(5, 5, 1); break;
-                    case 3: QUNROLLED(5, 5, 3); break;
-                    case 4: QUNROLLED(5, 5, 4); break;
-                    default: QUNROLLED(5, 5, 2); break;
-                }
-            }
+                if (h->kn_occ == 1) QUNROLLED(5, 5, 1); else QUNROLLED(5, 5, 2);
+            }  // (3 and 4 waves per SIMD were measured and lost: profiles/r03/ab_qary_occ.log; not compiled in)
 #undef QUNROLLED
             else if (h->special && tree_nb) {
                 // the Kyber shape: tree walk for the rows of 6 coefficient edges, the generic wave kernel for any others
@@ -1383,7 +1373,7 @@ int scaldpc_qary_configure(scaldpc_qary *h, const char *key, const char *value)
     else if (!strcmp(key, "var_small"))
         h->kn_var_small = atoi(value) != 0;
     else if (!strcmp(key, "occ"))
-        h->kn_occ = std::max(1, std::min(4, atoi(value)));
+        h->kn_occ = atoi(value) <= 1 ? 1 : 2;
     else
         return fail(SCALDPC_EINVAL, "unknown knob %s", key);
     return 0;
