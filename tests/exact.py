@@ -225,3 +225,119 @@ def pmf_to_llr64(pmf):
     p = np.asarray(pmf, dtype=np.float64)
     with np.errstate(divide="ignore"):
         return np.log(p.max(axis=-1, keepdims=True) / p)
+
+
+# ------------------------------------------------ exact inference on LARGE trees (no enumeration)
+def tree_exact_binary(H, probs, synds):
+    """Exact posteriors on a cycle-free Tanner graph of ANY size, by variable elimination in the log-probability domain:
+    every node passes a PAIR (log weight of "0", log weight of "1") to its parent (leaves to roots), then the roots pass
+    the complementary pairs back down; a check folds its children's pairs into (log weight of even parity, of odd parity)
+    with logaddexp [sum-product] or max [min-sum's max-product] -- no tanh, no atanh, no LLR differences, float64, so it
+    shares neither formulation nor precision with the decoders.  Agrees with `binary_exact` where both apply.
+    H dense 0/1 [m, n]; probs [n]; synds uint8 [batch, m].  Returns dict(sp [batch, n], ms [batch, n])."""
+    H = np.asarray(H) & 1
+    m, n = H.shape
+    assert is_forest(H)
+    synds = np.atleast_2d(np.asarray(synds)).astype(np.int64) & 1
+    B = synds.shape[0]
+    p = np.asarray(probs, dtype=np.float64)
+    with np.errstate(divide="ignore"):
+        prior = np.stack([np.log1p(-p), np.log(p)], axis=0)  # [2, n]
+    var_checks = [np.flatnonzero(H[:, v]) for v in range(n)]
+    check_vars = [np.flatnonzero(H[r]) for r in range(m)]
+    # root every component at its lowest-numbered variable; BFS order; isolated checks (no variable) cannot occur in a decoder
+    parent_of_var = [-2] * n  # check above the variable (-1: root)
+    parent_of_check = [-1] * m  # variable above the check
+    order = []  # ("v", id) / ("c", id) top-down
+    for root in range(n):
+        if parent_of_var[root] != -2:
+            continue
+        parent_of_var[root] = -1
+        queue = [("v", root)]
+        while queue:
+            kind, x = queue.pop(0)
+            order.append((kind, x))
+            if kind == "v":
+                for c in var_checks[x]:
+                    if c != parent_of_var[x]:
+                        parent_of_check[c] = x
+                        queue.append(("c", int(c)))
+            else:
+                for v in check_vars[x]:
+                    if v != parent_of_check[x]:
+                        parent_of_var[v] = x
+                        queue.append(("v", int(v)))
+    out = {}
+    for name, comb in (("sp", np.logaddexp), ("ms", np.maximum)):
+        def fold(a, b):  # parity pair (even, odd) of two independent groups
+            with np.errstate(invalid="ignore"):
+                return np.stack([comb(a[0] + b[0], a[1] + b[1]), comb(a[0] + b[1], a[1] + b[0])])
+        zero = np.stack([np.zeros(B), np.full(B, -np.inf)])  # an empty group has even parity
+        up_v = [None] * n  # variable -> its parent check: pair [2, B]
+        up_c = [None] * m  # check -> its parent variable
+        for kind, x in reversed(order):
+            if kind == "v":
+                w = np.repeat(prior[:, x][:, None], B, axis=1)
+                for c in var_checks[x]:
+                    if c != parent_of_var[x]:
+                        w = w + up_c[c]
+                up_v[x] = w
+            else:
+                acc = zero
+                for v in check_vars[x]:
+                    if v != parent_of_check[x]:
+                        acc = fold(acc, up_v[v])
+                s = synds[:, x]
+                # parent value t: children parity must be s ^ t
+                up_c[x] = np.stack([np.where(s == 0, acc[0], acc[1]), np.where(s == 0, acc[1], acc[0])])
+        down_v = [None] * n  # parent check -> variable
+        down_c = [None] * m  # parent variable -> check (the variable's belief without this check)
+        post = np.zeros((2, B, n))
+        for kind, x in order:
+            if kind == "v":
+                tot = np.repeat(prior[:, x][:, None], B, axis=1)
+                if parent_of_var[x] >= 0:
+                    tot = tot + down_v[x]
+                kids = [c for c in var_checks[x] if c != parent_of_var[x]]
+                for c in kids:
+                    tot = tot + up_c[c]
+                post[:, :, x] = tot
+                for c in kids:  # belief without check c (recomputed as a sum: no inf - inf)
+                    w = np.repeat(prior[:, x][:, None], B, axis=1)
+                    if parent_of_var[x] >= 0:
+                        w = w + down_v[x]
+                    for c2 in kids:
+                        if c2 != c:
+                            w = w + up_c[c2]
+                    down_c[c] = w
+            else:
+                kids = [v for v in check_vars[x] if v != parent_of_check[x]]
+                groups = [down_c[x]] + [up_v[v] for v in kids]  # the parent variable counts as a group too
+                pre = [zero]
+                for g in groups:
+                    pre.append(fold(pre[-1], g))
+                suf = [zero]
+                for g in reversed(groups):
+                    suf.append(fold(suf[-1], g))
+                suf = suf[::-1]  # suf[i] = fold of groups[i:]
+                s = synds[:, x]
+                for i, v in enumerate(kids, start=1):
+                    others = fold(pre[i], suf[i + 1])  # parity pair of everybody but kid i
+                    down_v[v] = np.stack([np.where(s == 0, others[0], others[1]), np.where(s == 0, others[1], others[0])])
+        with np.errstate(invalid="ignore"):
+            out[name] = post[0] - post[1]
+    return out
+
+
+def random_binary_tree_sparse(rng, n_vars, max_check_degree=5):
+    """As random_binary_tree, for thousands of variables: returns (rows: list of column lists, n)."""
+    rows = []
+    nv = 1
+    while nv < n_vars:
+        k = min(int(rng.randint(1, max_check_degree)), n_vars - nv)
+        rows.append([int(rng.randint(nv))] + list(range(nv, nv + k)))
+        nv += k
+    perm = rng.permutation(n_vars)
+    rows = [sorted(int(perm[c]) for c in cs) for cs in rows]
+    order = rng.permutation(len(rows))
+    return [rows[i] for i in order], n_vars

@@ -154,3 +154,50 @@ def test_special_decoder_finds_the_minimum_cost_assignment(oracle, seed):
     g = S.TannerGraph.from_dense(H)
     got = oracle.qary_special_batch(g, 2, 12, pmf_b, pmf_s, 2 * sum(H.shape))
     assert np.array_equal(got, best), (got, best)
+
+
+# ------------------------------------------------------------------------ large trees (no enumeration)
+def large_tree_case(n_vars, batch, seed, hard=0):
+    """A random cycle-free graph with thousands of variables, priors on both sides of 1/2, syndromes the priors allow, and
+    the exact posteriors from tests/exact.tree_exact_binary (elimination in the log-probability domain, float64).
+    Returns (TannerGraph, dense-free rows, probs, synds, exact dict, iterations that certainly suffice)."""
+    rng = np.random.RandomState(seed)
+    rows, n = exact.random_binary_tree_sparse(rng, n_vars, max_check_degree=6)
+    g = S.TannerGraph.from_row_supports(rows, n)
+    H = g.to_dense(np.int8)
+    probs = exact.random_priors(rng, n, hard=hard)
+    e = (rng.rand(batch, n) < 0.5).astype(np.uint8)
+    e[:, probs == 0.0] = 0
+    e[:, probs == 1.0] = 1
+    synds = g.syndrome(e)
+    ex = exact.tree_exact_binary(H, probs, synds)
+    return g, probs, synds, ex, 2 * (g.m + 2)  # (flooding needs at most the diameter; the node count bounds it)
+
+
+def test_the_two_answer_keys_agree():
+    """tree_exact_binary (elimination, any size) against binary_exact (enumeration) where both apply."""
+    rng = np.random.RandomState(5)
+    for trial in range(8):
+        n = int(rng.randint(5, 15))
+        H = exact.random_binary_tree(rng, n, 5)
+        probs = exact.random_priors(rng, n, hard=(trial % 3 == 2) * 2)
+        synds = exact.feasible_syndromes(rng, H, probs, 7)
+        a, b = exact.binary_exact(H, probs, synds), exact.tree_exact_binary(H, probs, synds)
+        for k in ("sp", "ms"):
+            fin = np.isfinite(a[k])
+            assert np.array_equal(np.isfinite(b[k]), fin) and np.array_equal(np.sign(a[k][~fin]), np.sign(b[k][~fin]))
+            assert np.allclose(a[k][fin], b[k][fin], rtol=1e-10, atol=1e-10)
+
+
+@pytest.mark.parametrize("hard", [0, 5])
+def test_large_tree(oracle, hard):
+    """700 variables, depth far beyond what enumeration reaches: every oracle method against the exact posteriors."""
+    g, probs, synds, ex, _ = large_tree_case(700, 9, seed=77 + hard, hard=hard)
+    # iterations: the tree's depth is O(log n) for this construction; 120 is far more than enough and keeps the test quick
+    # measured: float64 methods 1e-13 relative, float32 5e-7 (also at 6000 variables); held to 1e-9 / 2e-5
+    for methods, key in ((SUM_PRODUCT, "sp"), (MIN_SUM, "ms")):
+        for method, dtype, _, _ in methods:
+            tol = 1e-9 if dtype == "f64" else 2e-5
+            with np.errstate(divide="ignore", invalid="ignore"):
+                r = oracle.bp_decode_batch(g, probs, synds, 0, 120, method, dtype=dtype, threads=4, early_exit=False)
+            exact.check_binary_llr(r["llr"], r["bits"], ex[key], tol, tol, f"{method}/{dtype} large tree")

@@ -13,7 +13,7 @@ import numpy as np
 import pytest
 
 import exact
-from test_exact_inference import qary_tree_case, rep_code_case, special_tree_case
+from test_exact_inference import large_tree_case, qary_tree_case, rep_code_case, special_tree_case
 
 pytestmark = pytest.mark.gpu
 S = importlib.import_module("sca-ldpc_amd")
@@ -64,6 +64,32 @@ def test_random_trees(method, path):
         got = hip_decode(H, probs, synds, method, 2 * (H.shape[0] + n), path)
         worst = max(worst, exact.check_binary_llr(got["llr"], got["bits"], ex[key], rtol, atol, f"{method} {path} seed {seed}"))
     print(f"{method} {path}: worst |dL| vs exact = {worst:.3e}")
+
+
+@pytest.mark.parametrize("path", ["auto", "edge"])
+@pytest.mark.parametrize("method", ["product_sum", "min_sum"])
+def test_large_tree(method, path):
+    """A cycle-free graph of 6000 variables (E = 7984: too large for the LDS-resident decoder, so `auto` takes the
+    64-codeword-tile kernels the BASELINE configs run on, with their degree buckets, two stream lanes and, here, the first
+    iteration without its check pass) against the exact posteriors of tests/exact.tree_exact_binary: 70 codewords on the
+    tile kernels, 5 on the row-parallel ones; +-inf priors included; early exit on for half the calls (converged results must
+    still be exact once the loop has run past the tree's depth -- it has not before, so only fixed-iteration runs are
+    compared on values, early-exit runs on their flags)."""
+    g, probs, synds, ex, _ = large_tree_case(6000, 70, seed=321, hard=6)
+    rtol, atol, key = TOL[method]
+    nb = 70 if path == "auto" else 5
+    with np.errstate(divide="ignore"):
+        dec = bp.bp_decoder(g, max_iter=150, bp_method=method, channel_probs=probs)
+    dec.configure(path=path)
+    got = dec.decode_batch(synds[:nb], early_exit=False, want_llr=True)
+    assert dec.last_stats()["row_parallel"] == (nb if path == "edge" else 0)
+    worst = exact.check_binary_llr(got["llr"], got["bits"], ex[key][:nb], rtol, atol, f"{method} {path} large tree")
+    assert got["converged"].all()
+    early = dec.decode_batch(synds[:nb], early_exit=True, want_llr=True)
+    assert early["converged"].all() and (early["iters"] <= 150).all()
+    assert np.array_equal(g.syndrome(early["bits"]), synds[:nb])
+    dec.close()
+    print(f"{method} {path}: 6000-variable tree, worst |dL| vs exact = {worst:.3e}")
 
 
 def test_single_decode_attributes_are_the_exact_marginals():
