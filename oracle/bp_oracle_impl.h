@@ -35,7 +35,8 @@
  * holds any.  ...pinned on cycle-free graphs by tests/test_exact_inference*.py: BP is
  * exact on trees, and every method / precision here (and the HIP path, in the GPU
  * suite) reproduces the enumerated marginals / min-cost differences on rep_code(13)
- * for every syndrome and on random trees, incl. p = 0 / 1 priors.
+ * for every syndrome and on random trees, incl. p = 0 / 1 priors; on a 700-variable tree
+ * against an enumeration-free exact solver (tests/exact.tree_exact_binary).
  */
 
 #define CAT_(a, b) a##_##b
