@@ -341,3 +341,109 @@ def random_binary_tree_sparse(rng, n_vars, max_check_degree=5):
     rows = [sorted(int(perm[c]) for c in cs) for cs in rows]
     order = rng.permutation(len(rows))
     return [rows[i] for i in order], n_vars
+
+
+def tree_exact_qary(H, llr_by_var, B):
+    """Min-marginals of the q-ary cost model on a cycle-free H (entries in {-1, 0, 1}) of any size, by (min, +) elimination:
+    a check folds its children's cost tables into a table over their SIGNED PARTIAL SUM (integer states, range +-k*B);
+    the parent's symbol x then needs partial sum = -h_p * x.  All variables share the alphabet [-B, B].
+    Returns minmarg float64 [N, 2B+1]: minmarg[v][q] = cost of the cheapest valid assignment with x_v = q - B
+    (inf if none).  The decoders' decision for v is argmin of that row (decoder.rs:654-657) wherever it is unique."""
+    H = np.asarray(H, dtype=np.int64)
+    R, N = H.shape
+    assert is_forest(H)
+    Q = 2 * B + 1
+    cost = [np.asarray(llr_by_var[v], dtype=np.float64) for v in range(N)]
+    var_checks = [np.flatnonzero(H[:, v]) for v in range(N)]
+    check_vars = [np.flatnonzero(H[r]) for r in range(R)]
+    pv, pc, order = [-2] * N, [-1] * R, []
+    for root in range(N):
+        if pv[root] != -2:
+            continue
+        pv[root] = -1
+        queue = [("v", root)]
+        while queue:
+            kind, x = queue.pop(0)
+            order.append((kind, x))
+            if kind == "v":
+                for c in var_checks[x]:
+                    if c != pv[x]:
+                        pc[c] = x
+                        queue.append(("c", int(c)))
+            else:
+                for v in check_vars[x]:
+                    if v != pc[x]:
+                        pv[v] = x
+                        queue.append(("v", int(v)))
+
+    def conv(a, b):  # (min, +) convolution of two tables over integer sums, each centred (index = sum + half)
+        out = np.full(a.size + b.size - 1, np.inf)
+        for i, ai in enumerate(a):
+            if np.isfinite(ai):
+                out[i : i + b.size] = np.minimum(out[i : i + b.size], ai + b)
+        return out
+
+    def signed(tab, h):  # table of h * x given the table of x
+        return tab if h > 0 else tab[::-1]
+
+    up_v, up_c = [None] * N, [None] * R
+    for kind, x in reversed(order):
+        if kind == "v":
+            t = cost[x].copy()
+            for c in var_checks[x]:
+                if c != pv[x]:
+                    t = t + up_c[c]
+            up_v[x] = t
+        else:
+            acc = np.zeros(1)
+            for v in check_vars[x]:
+                if v != pc[x]:
+                    acc = conv(acc, signed(up_v[v], H[x, v]))
+            half = (acc.size - 1) // 2
+            hp = H[x, pc[x]]
+            t = np.full(Q, np.inf)
+            for q in range(Q):
+                need = -hp * (q - B)  # children's signed sum
+                if abs(need) <= half:
+                    t[q] = acc[need + half]
+            up_c[x] = t
+    down_v, down_c = [None] * N, [None] * R
+    mm = np.zeros((N, Q))
+    for kind, x in order:
+        if kind == "v":
+            tot = cost[x].copy()
+            if pv[x] >= 0:
+                tot = tot + down_v[x]
+            kids = [c for c in var_checks[x] if c != pv[x]]
+            for c in kids:
+                tot = tot + up_c[c]
+            mm[x] = tot
+            for c in kids:
+                w = cost[x].copy()
+                if pv[x] >= 0:
+                    w = w + down_v[x]
+                for c2 in kids:
+                    if c2 != c:
+                        w = w + up_c[c2]
+                down_c[c] = w
+        else:
+            kids = [v for v in check_vars[x] if v != pc[x]]
+            groups = [signed(down_c[x], H[x, pc[x]])] + [signed(up_v[v], H[x, v]) for v in kids]
+            pre = [np.zeros(1)]
+            for g in groups:
+                pre.append(conv(pre[-1], g))
+            suf = [np.zeros(1)]
+            for g in reversed(groups):
+                suf.append(conv(suf[-1], g))
+            suf = suf[::-1]
+            for i, v in enumerate(kids, start=1):
+                others = conv(pre[i], suf[i + 1])
+                half = (others.size - 1) // 2
+                hv = H[x, v]
+                t = np.full(Q, np.inf)
+                for q in range(Q):
+                    need = -hv * (q - B)
+                    if abs(need) <= half:
+                        t[q] = others[need + half]
+                down_v[v] = t
+    return mm

@@ -201,3 +201,45 @@ def test_large_tree(oracle, hard):
             with np.errstate(divide="ignore", invalid="ignore"):
                 r = oracle.bp_decode_batch(g, probs, synds, 0, 120, method, dtype=dtype, threads=4, early_exit=False)
             exact.check_binary_llr(r["llr"], r["bits"], ex[key], tol, tol, f"{method}/{dtype} large tree")
+
+
+def large_qary_tree_case(n_vars, B, batch, seed):
+    """A +-1 tree of a few hundred variables with the exact min-marginals of every variable (tests/exact.tree_exact_qary).
+    Returns (H int8, pmf float32 [batch, N, Q], decisions int8 [batch, N], decided bool [batch, N]): `decided` marks the
+    variables whose best symbol beats the second best by a margin clear of fp32 rounding (sums of N costs)."""
+    rng = np.random.RandomState(seed)
+    Q = 2 * B + 1
+    rows, n = exact.random_binary_tree_sparse(rng, n_vars, max_check_degree=5)
+    H = np.zeros((len(rows), n), dtype=np.int8)
+    for r, cs in enumerate(rows):
+        H[r, cs] = rng.choice(np.array([-1, 1], dtype=np.int8), size=len(cs))
+    pmf = rng.dirichlet(np.ones(Q) * 1.2, size=(batch, n)).astype(np.float32)
+    dec = np.zeros((batch, n), dtype=np.int8)
+    ok = np.zeros((batch, n), dtype=bool)
+    for b in range(batch):
+        mm = exact.tree_exact_qary(H, exact.pmf_to_llr64(pmf[b]), B)
+        srt = np.sort(mm, axis=1)
+        dec[b] = mm.argmin(axis=1) - B
+        ok[b] = srt[:, 1] - srt[:, 0] > 1e-3 * max(1.0, float(srt[:, 0].max()))
+    return H, pmf, dec, ok
+
+
+def test_the_two_qary_answer_keys_agree():
+    rng = np.random.RandomState(9)
+    for trial in range(8):
+        B = 1 + trial % 2
+        n = int(rng.randint(4, 9 if B == 1 else 7))
+        H = exact.random_qary_tree(rng, n, 4)
+        llr = exact.pmf_to_llr64(rng.dirichlet(np.ones(2 * B + 1) * 1.5, size=n))
+        best, cost, gap = exact.qary_exact(H, llr, [B] * n)
+        mm = exact.tree_exact_qary(H, llr, B)
+        assert np.allclose(mm.min(axis=1), cost) and (gap < 1e-9 or np.array_equal(mm.argmin(axis=1) - B, best))
+
+
+@pytest.mark.parametrize("B", [1, 2])
+def test_qary_large_tree(oracle, B):
+    """250 variables: the oracle's symbols are the arg-minima of the exact min-marginals wherever those are clear."""
+    H, pmf, dec, ok = large_qary_tree_case(250, B, 6, seed=40 + B)
+    g = S.TannerGraph.from_dense(H)
+    got = oracle.qary_min_sum_batch(g, 2 * B + 1, pmf, 80, threads=4)
+    assert ok.mean() > 0.9 and np.array_equal(got[ok], dec[ok])

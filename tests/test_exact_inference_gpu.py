@@ -13,7 +13,7 @@ import numpy as np
 import pytest
 
 import exact
-from test_exact_inference import large_tree_case, qary_tree_case, rep_code_case, special_tree_case
+from test_exact_inference import large_qary_tree_case, large_tree_case, qary_tree_case, rep_code_case, special_tree_case
 
 pytestmark = pytest.mark.gpu
 S = importlib.import_module("sca-ldpc_amd")
@@ -143,3 +143,19 @@ def test_special_decoder_finds_the_minimum_cost_assignment(knobs):
         got = dec.min_sum_batch(pmf_b, pmf_s)
         dec.close()
         assert np.array_equal(got, best), (seed, knobs)
+
+
+@pytest.mark.parametrize("knobs", [dict(), dict(wave=0), dict(wave=1, unroll=0), dict(var_small=0, llr_tiled=0)])
+@pytest.mark.parametrize("B", [1, 2])
+def test_qary_large_tree(B, knobs):
+    """A +-1 tree of 250 variables (checks of up to 5 edges): the decoder's symbols are the arg-minima of the exact
+    min-marginals (tests/exact.tree_exact_qary: (min, +) elimination over integer partial sums, float64) wherever those
+    are clear of fp32 rounding -- every kernel form, 70 channel outputs."""
+    H, pmf, dec_exact, ok = large_qary_tree_case(250, B, 70, seed=40 + B)
+    R, N = H.shape
+    nz = H != 0
+    d = qary.decoder_class(f"DecoderN{N}R{R}V{int(nz.sum(axis=0).max())}C{int(nz.sum(axis=1).max())}B{B}")(H, 80)
+    d.configure(**knobs)
+    got = d.min_sum_batch(pmf)
+    d.close()
+    assert ok.mean() > 0.9 and np.array_equal(got[ok], dec_exact[ok])
