@@ -22,7 +22,8 @@
  * oracle_qary_special is "parity unpinned" by the reference.  ...pinned on cycle-free
  * graphs by tests/test_exact_inference*.py: on tree-shaped [H' | +-I] (B = 2, BSUM = 12)
  * its decision, and the HIP path's, is the enumerated minimum-cost valid assignment;
- * the same holds for oracle_qary_min_sum on random +-1 trees with B = 1, 2.
+ * the same holds for oracle_qary_min_sum on random +-1 trees with B = 1, 2, up to 250
+ * variables against exact min-marginals ((min,+) elimination, tests/exact.tree_exact_qary).
  */
 #include <math.h>
 #include <stdint.h>
