@@ -346,13 +346,14 @@ def random_binary_tree_sparse(rng, n_vars, max_check_degree=5):
 def tree_exact_qary(H, llr_by_var, B):
     """Min-marginals of the q-ary cost model on a cycle-free H (entries in {-1, 0, 1}) of any size, by (min, +) elimination:
     a check folds its children's cost tables into a table over their SIGNED PARTIAL SUM (integer states, range +-k*B);
-    the parent's symbol x then needs partial sum = -h_p * x.  All variables share the alphabet [-B, B].
-    Returns minmarg float64 [N, 2B+1]: minmarg[v][q] = cost of the cheapest valid assignment with x_v = q - B
-    (inf if none).  The decoders' decision for v is argmin of that row (decoder.rs:654-657) wherever it is unique."""
+    the parent's symbol x then needs partial sum = -h_p * x.  B: one alphabet bound for all variables, or a list with
+    one per variable (DecoderSpecial: B for the coefficient variables, BSUM for the row-sum variables).
+    Returns minmarg float64 [N, 2B+1] (a list of rows for per-variable alphabets): minmarg[v][q] = cost of the
+    cheapest valid assignment with x_v = q - B_v (inf if none).  The decoders' decision for v is argmin of that row (decoder.rs:654-657) wherever it is unique."""
     H = np.asarray(H, dtype=np.int64)
     R, N = H.shape
     assert is_forest(H)
-    Q = 2 * B + 1
+    Bv = [int(B)] * N if np.isscalar(B) else [int(x) for x in B]  # per-variable alphabets (DecoderSpecial: B, then BSUM)
     cost = [np.asarray(llr_by_var[v], dtype=np.float64) for v in range(N)]
     var_checks = [np.flatnonzero(H[:, v]) for v in range(N)]
     check_vars = [np.flatnonzero(H[r]) for r in range(R)]
@@ -401,14 +402,15 @@ def tree_exact_qary(H, llr_by_var, B):
                     acc = conv(acc, signed(up_v[v], H[x, v]))
             half = (acc.size - 1) // 2
             hp = H[x, pc[x]]
-            t = np.full(Q, np.inf)
-            for q in range(Q):
-                need = -hp * (q - B)  # children's signed sum
+            Bp = Bv[pc[x]]
+            t = np.full(2 * Bp + 1, np.inf)
+            for q in range(2 * Bp + 1):
+                need = -hp * (q - Bp)  # children's signed sum
                 if abs(need) <= half:
                     t[q] = acc[need + half]
             up_c[x] = t
     down_v, down_c = [None] * N, [None] * R
-    mm = np.zeros((N, Q))
+    mm = [None] * N
     for kind, x in order:
         if kind == "v":
             tot = cost[x].copy()
@@ -440,10 +442,10 @@ def tree_exact_qary(H, llr_by_var, B):
                 others = conv(pre[i], suf[i + 1])
                 half = (others.size - 1) // 2
                 hv = H[x, v]
-                t = np.full(Q, np.inf)
-                for q in range(Q):
-                    need = -hv * (q - B)
+                t = np.full(2 * Bv[v] + 1, np.inf)
+                for q in range(2 * Bv[v] + 1):
+                    need = -hv * (q - Bv[v])
                     if abs(need) <= half:
                         t[q] = others[need + half]
                 down_v[v] = t
-    return mm
+    return np.stack(mm) if np.isscalar(B) else mm

@@ -243,3 +243,38 @@ def test_qary_large_tree(oracle, B):
     g = S.TannerGraph.from_dense(H)
     got = oracle.qary_min_sum_batch(g, 2 * B + 1, pmf, 80, threads=4)
     assert ok.mean() > 0.9 and np.array_equal(got[ok], dec[ok])
+
+
+def large_special_tree_case(R, batch, seed):
+    """DecoderSpecial on a cycle-free [H' | +-I] of R checks (2-6 coefficient edges each, chained through shared
+    coefficient variables), B = 2, BSUM = 12, with the exact min-marginals (per-variable alphabets)."""
+    rng = np.random.RandomState(seed)
+    coeffs = [int(rng.randint(2, 7)) for _ in range(R)]
+    coeffs[0] = 6  # (at least one row of six coefficient edges: the tree-walk kernel's shape)
+    H = exact.random_special_tree(rng, R, coeffs)
+    H[:, H.shape[1] - R:] *= rng.choice(np.array([-1, 1], dtype=np.int8), size=R)[None, :]
+    BV = H.shape[1] - R
+    pb = rng.dirichlet(np.ones(5) * 1.2, size=(batch, BV)).astype(np.float32)
+    ps = rng.dirichlet(np.ones(25) * 0.6, size=(batch, R)).astype(np.float32)
+    dec = np.zeros((batch, H.shape[1]), dtype=np.int8)
+    ok = np.zeros((batch, H.shape[1]), dtype=bool)
+    alph = [2] * BV + [12] * R
+    for b in range(batch):
+        llr = [exact.pmf_to_llr64(pb[b][v]) for v in range(BV)] + [exact.pmf_to_llr64(ps[b][r]) for r in range(R)]
+        mm = exact.tree_exact_qary(H, llr, alph)
+        top = max(float(np.min(m)) for m in mm)
+        for v, m in enumerate(mm):
+            srt = np.sort(m)
+            dec[b, v] = int(np.argmin(m)) - alph[v]
+            ok[b, v] = srt[1] - srt[0] > 1e-3 * max(1.0, top)
+    return H, pb, ps, dec, ok
+
+
+def test_special_large_tree(oracle):
+    """40 checks, ~120 coefficient variables: far beyond enumeration (5^120); the oracle's symbols are the arg-minima of the
+    exact min-marginals wherever those are clear."""
+    H, pb, ps, dec, ok = large_special_tree_case(40, 5, seed=70)
+    assert exact.is_forest(H)
+    g = S.TannerGraph.from_dense(H)
+    got = oracle.qary_special_batch(g, 2, 12, pb, ps, 100, threads=4)
+    assert ok.mean() > 0.85 and np.array_equal(got[ok], dec[ok])

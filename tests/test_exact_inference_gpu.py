@@ -13,7 +13,7 @@ import numpy as np
 import pytest
 
 import exact
-from test_exact_inference import large_qary_tree_case, large_tree_case, qary_tree_case, rep_code_case, special_tree_case
+from test_exact_inference import large_qary_tree_case, large_special_tree_case, large_tree_case, qary_tree_case, rep_code_case, special_tree_case
 
 pytestmark = pytest.mark.gpu
 S = importlib.import_module("sca-ldpc_amd")
@@ -159,3 +159,16 @@ def test_qary_large_tree(B, knobs):
     got = d.min_sum_batch(pmf)
     d.close()
     assert ok.mean() > 0.9 and np.array_equal(got[ok], dec_exact[ok])
+
+
+@pytest.mark.parametrize("knobs", [dict(), dict(tree=0), dict(wave=0), dict(var_small=0, llr_tiled=0)])
+def test_special_large_tree(knobs):
+    """DecoderSpecial (B = 2, BSUM = 12) on a cycle-free [H' | +-I] of 40 checks with 2-6 coefficient edges each: symbols =
+    arg-minima of the exact min-marginals wherever those are clear; tree-walk, wave and lane kernels; 66 channel outputs."""
+    H, pb, ps, dec_exact, ok = large_special_tree_case(40, 66, seed=70)
+    R, N = H.shape
+    d = qary.decoder_class(f"DecoderN{N}R{R}SW6")(H, 100)
+    d.configure(**knobs)
+    got = d.min_sum_batch(pb, ps)
+    d.close()
+    assert ok.mean() > 0.85 and np.array_equal(got[ok], dec_exact[ok])
