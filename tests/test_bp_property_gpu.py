@@ -151,14 +151,14 @@ def test_random_hqc_shaped_instances(oracle, N, W, rfrac, omega, eps, batch, met
     finally:
         for k in keys:
             os.environ.pop(k, None)
-    tol, _ = _own_sensitivity(oracle, H, probs, msg, 1, max_iter, method, early, ref)
+    tol, same64 = _own_sensitivity(oracle, H, probs, msg, 1, max_iter, method, early, ref)
     compare(got, ref, method, widened_tol=tol, tie_codewords=1 + batch // 64)
     if method == "product_sum":
         # the float64 reference form must cover at least 60 % of what the f32 oracle converged on (ties of the decision
         # rule may move a codeword's iteration count by one between float32 and float64, hence not 100 %)
         with np.errstate(divide="ignore", invalid="ignore"):
             check_reference_form(oracle, got, H, probs, msg, 1, max_iter, early, min_fraction=reference_floor(ref, 0.6),
-                                 threads=8, tol=max(1e-3, 2.0 * tol), label="hqc")
+                                 threads=8, tol=max(1e-3, 2.0 * tol), label="hqc", same_order64=same64)
 
 
 def test_the_reference_form_checks_compared_something():
