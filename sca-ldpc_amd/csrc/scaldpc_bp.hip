@@ -77,6 +77,7 @@ struct Knobs {
     int first_fused = 1;      // iteration 1 of the tile kernels without its check pass (k_var_first from the first-message table); 0 = check pass + plain variable pass
     int test_overlap = 0;     // early-exit tile groups: 1 = the convergence test of iteration it runs on a side stream beside the check pass of it + 1 (A/B knob: measured 3.4 % SLOWER on the config-5 sweep, profiles/r03/ab_test_overlap.log)
     int var_form = 1;         // k_var: 0 = ids fetched edge by edge, 1 = all ids up front as wide scalar loads (default)
+    int minsum_rec = 1;       // min-sum on the tile kernels: check pass writes per-row records + lane masks instead of messages (k_check_minsum_rec / k_var_rec); 0 = message form
 };
 
 struct scaldpc_bp {
@@ -173,6 +174,12 @@ struct scaldpc_bp {
     // of the re-laid edge list; valid for one (method, alpha of iteration 1) and the current priors / graph
     int2 *d_first_tab = nullptr;
     size_t cap_first = 0;
+    // record form of min-sum on the tile kernels: per (tile, row) the two magnitudes, per (tile, edge) two lane masks;
+    // d_csc_row = row of every position of the re-laid edge list (inside d_tile_tab)
+    float *d_rec = nullptr;
+    ulonglong2 *d_mask = nullptr;
+    int cap_rec_group = 0;
+    int *d_csc_row = nullptr;
     bool first_valid = false;
     int first_method = -1;
     float first_alpha = 0.0f;
@@ -227,6 +234,7 @@ bool set_knob(Knobs &k, const char *key, const char *val)
     else if (!strcmp(key, "fuse_finalize")) k.fuse_finalize = (int)x != 0;
     else if (!strcmp(key, "test_overlap")) k.test_overlap = (int)x != 0;
     else if (!strcmp(key, "first_fused")) k.first_fused = (int)x != 0;
+    else if (!strcmp(key, "minsum_rec")) k.minsum_rec = (int)x != 0;
     else if (!strcmp(key, "fuse_test")) k.fuse_test = (int)x != 0;
     else return false;
     return true;
@@ -237,7 +245,7 @@ void knobs_from_env(Knobs &k)
     static const char *const names[][2] = {{"SCALDPC_PATH", "path"}, {"SCALDPC_SPLIT", "split"},
                                            {"SCALDPC_GROUP_MB", "group_mb"}, {"SCALDPC_EL_MAX", "el_max"},
                                            {"SCALDPC_EL_FUSE", "el_fuse"}, {"SCALDPC_COMPACT_AFTER", "compact_after"},
-                                           {"SCALDPC_VAR_ORDER", "var_order"}, {"SCALDPC_VAR_FORM", "var_form"}, {"SCALDPC_SPECULATE", "speculate"}, {"SCALDPC_FUSE_FINALIZE", "fuse_finalize"}, {"SCALDPC_TEST_OVERLAP", "test_overlap"}, {"SCALDPC_FIRST_FUSED", "first_fused"}, {"SCALDPC_FUSE_TEST", "fuse_test"}};
+                                           {"SCALDPC_VAR_ORDER", "var_order"}, {"SCALDPC_VAR_FORM", "var_form"}, {"SCALDPC_SPECULATE", "speculate"}, {"SCALDPC_FUSE_FINALIZE", "fuse_finalize"}, {"SCALDPC_TEST_OVERLAP", "test_overlap"}, {"SCALDPC_FIRST_FUSED", "first_fused"}, {"SCALDPC_FUSE_TEST", "fuse_test"}, {"SCALDPC_MINSUM_REC", "minsum_rec"}};
     for (auto &nm : names)
         if (const char *e = getenv(nm[0])) (void)set_knob(k, nm[1], e);
     if (getenv("SCALDPC_MINSUM_LOOP")) k.minsum_loop = 1;  // presence switches it on, as before
@@ -403,6 +411,7 @@ int ensure_tile_tables(scaldpc_bp *h)
     };
     const size_t o_var_meta = reserve((size_t)4 * VAR_REC * hv.bk.blk[hv.bk.nb] + 4), o_csc_list = reserve((size_t)h->E + 1 + 64);
     const size_t o_row_list = reserve((size_t)16 * hr.bk.blk[hr.bk.nb] + 4);
+    const size_t o_csc_row = reserve((size_t)h->E + 1 + 64);
     int *host = stage_buffer(total);
     if (!host) return fail(SCALDPC_ENOMEM, "out of host memory");
     for (int b = 0; b < hr.bk.nb; b++) {
@@ -417,8 +426,11 @@ int ensure_tile_tables(scaldpc_bp *h)
             md[3] = hr.bk.maxd[b];
         }
     }
-    int *meta = host + o_var_meta, *relaid = host + o_csc_list;
+    int *meta = host + o_var_meta, *relaid = host + o_csc_list, *relaid_row = host + o_csc_row;
     int pos = 0;
+    pvec<int> edge_row((size_t)h->E);
+    for (int r = 0; r < h->m; r++)
+        for (int e = row_ptr[r]; e < row_ptr[r + 1]; e++) edge_row[e] = r;
     // launch order of the columns: the bucket lists are sorted by degree, ascending column id inside a
     // degree.  var_order = 1 re-sorts each run of equal degree by the column's FIRST edge id, so that
     // neighbouring waves of a launch start their gathers in neighbouring rows of the message array
@@ -459,7 +471,10 @@ int ensure_tile_tables(scaldpc_bp *h)
             md[1] = pos;
             md[2] = d;
             md[3] = hv.bk.maxd[b];
-            for (int k = 0; k < d; k++) relaid[pos + k] = csc_edge[(size_t)col_ptr[v] + k];
+            for (int k = 0; k < d; k++) {
+                relaid[pos + k] = csc_edge[(size_t)col_ptr[v] + k];
+                relaid_row[pos + k] = edge_row[relaid[pos + k]];
+            }
             for (int k = 0; k < VAR_INLINE; k++) md[4 + k] = k < d ? relaid[pos + k] : 0;
             pos += d;
         }
@@ -476,6 +491,7 @@ int ensure_tile_tables(scaldpc_bp *h)
     h->d_var_meta = h->d_tile_tab + o_var_meta;
     h->d_csc_list = h->d_tile_tab + o_csc_list;
     h->d_row_list = h->d_tile_tab + o_row_list;
+    h->d_csc_row = h->d_tile_tab + o_csc_row;
     return 0;
 }
 
@@ -565,10 +581,25 @@ int ensure_el_tables(scaldpc_bp *h)
     return el_upload(h);
 }
 
-// message array of the tile path, G tiles
-int ensure_msg(scaldpc_bp *h, int G)
+// Min-sum in its record form (k_check_minsum_rec / k_var_rec)?  Rows and columns that live in registers, the
+// exact-degree check kernels, the scalar-id variable kernel.
+bool rec_form(const scaldpc_bp *h, int method)
+{
+    return method == SCALDPC_BP_MIN_SUM && h->kn.minsum_rec && h->kn.minsum_loop == 0 && h->kn.var_form == 1 && h->E > 0 &&
+           h->max_row_deg <= 64 && h->max_col_deg <= 64 && !h->hg_var.has_generic;
+}
+
+// message array of the tile path, G tiles (and the records of the min-sum record form)
+int ensure_msg(scaldpc_bp *h, int G, int method)
 {
     SC_TRY(ensure_tile_tables(h));
+    if (rec_form(h, method) && G > h->cap_rec_group) {  // (append_rows resets cap_rec_group too)
+        dev_free(h->d_rec); dev_free(h->d_mask);
+        h->cap_rec_group = 0;
+        SC_TRY(dev_alloc(&h->d_rec, (size_t)G * h->m * 2 * TW));
+        SC_TRY(dev_alloc(&h->d_mask, (size_t)G * h->E));
+        h->cap_rec_group = G;
+    }
     if (G > h->cap_group) {  // (append_rows resets cap_group: the arrays are sized by E)
         dev_free(h->d_msg); dev_free(h->d_scratch);
         h->cap_group = 0;
@@ -641,7 +672,28 @@ int launch_check(scaldpc_bp *h, int method, float alpha, int G, const u64 *synd_
     hipLaunchKernelGGL((k_check_minsum<W, F>), grid, dim3(256), 0, s, h->d_row_ptr, msg0, synd_g, done_g, skip_done, \
                        h->m, h->E, alpha, h->d_col_idx, h->d_prior)
         const bool loop_form = h->kn.minsum_loop != 0;  // A/B knob
-        if (h->max_row_deg <= ROW_CAP && !loop_form) {
+        if (rec_form(h, method)) {
+            dim3 gridx(h->row_bk.blk[h->row_bk.nb], G);
+            float *const rec0 = h->d_rec + (size_t)tile0 * h->m * 2 * TW;
+            ulonglong2 *const mask0 = h->d_mask + (size_t)tile0 * h->E;
+#define MSR_LAUNCH(CAP, F)                                                                                          \
+    hipLaunchKernelGGL((k_check_minsum_rec<CAP, F>), gridx, dim3(256), 0, s, h->d_row_list, msg0, synd_g, done_g, skip_done, \
+                       h->m, h->E, alpha, h->d_col_idx, h->d_prior, rec0, mask0)
+#define MSR_PAR(CAP)                                                                                                \
+    hipLaunchKernelGGL((k_check_minsum_rec<CAP, false, true>), gridx, dim3(256), 0, s, h->d_row_list, msg0, synd_g, done_g, \
+                       skip_done, h->m, h->E, alpha, h->d_col_idx, h->d_prior, rec0, mask0, *ft)
+            if (ft && !first) {
+                if (h->max_row_deg <= 16) MSR_PAR(16); else if (h->max_row_deg <= 32) MSR_PAR(32); else MSR_PAR(64);
+            } else if (h->max_row_deg <= 16) {
+                if (first) MSR_LAUNCH(16, true); else MSR_LAUNCH(16, false);
+            } else if (h->max_row_deg <= 32) {
+                if (first) MSR_LAUNCH(32, true); else MSR_LAUNCH(32, false);
+            } else {
+                if (first) MSR_LAUNCH(64, true); else MSR_LAUNCH(64, false);
+            }
+#undef MSR_PAR
+#undef MSR_LAUNCH
+        } else if (h->max_row_deg <= ROW_CAP && !loop_form) {
             dim3 gridx(h->row_bk.blk[h->row_bk.nb], G);
 #define MSX_LAUNCH(CAP, F)                                                                                          \
     hipLaunchKernelGGL((k_check_minsum_x<CAP, F>), gridx, dim3(256), 0, s, h->d_row_list, msg0, synd_g, done_g, skip_done, \
@@ -745,7 +797,7 @@ int ensure_first_table(scaldpc_bp *h, int method, float alpha1, hipStream_t s)
 
 // first_synd: non-null = iteration 1 without its check pass (the group's syndrome planes; ensure_first_table first)
 int launch_var(scaldpc_bp *h, int G, float *post_g, u64 *hard_g, const u64 *done_g, int skip_done, int write_out,
-               hipStream_t s, int tile0 = 0, const u64 *first_synd = nullptr)
+               hipStream_t s, int tile0 = 0, const u64 *first_synd = nullptr, bool rec = false)
 {
     dim3 grid(h->var_bk.blk[h->var_bk.nb], G);
     float *const msg0 = h->d_msg + (size_t)tile0 * h->E * TW;
@@ -763,6 +815,21 @@ int launch_var(scaldpc_bp *h, int G, float *post_g, u64 *hard_g, const u64 *done
         else
             VAR_FIRST(64);
 #undef VAR_FIRST
+        LAUNCH_CHECK();
+        return 0;
+    }
+    if (rec) {  // the check pass left records, not messages (rec_form)
+#define VAR_REC_LAUNCH(CAP)                                                                                         \
+    hipLaunchKernelGGL((k_var_rec<CAP>), grid, dim3(256), 0, s, h->d_var_meta, h->d_csc_list, h->d_csc_row, h->d_prior, msg0, \
+                       h->d_rec + (size_t)tile0 * h->m * 2 * TW, h->d_mask + (size_t)tile0 * h->E, post_g, hard_g, done_g,   \
+                       skip_done, h->n, h->m, h->E, write_out)
+        if (h->max_col_deg <= 16)
+            VAR_REC_LAUNCH(16);
+        else if (h->max_col_deg <= 32)
+            VAR_REC_LAUNCH(32);
+        else
+            VAR_REC_LAUNCH(64);
+#undef VAR_REC_LAUNCH
         LAUNCH_CHECK();
         return 0;
     }
@@ -1039,7 +1106,7 @@ int iterate_tiles(scaldpc_bp *h, const TileState &st, int g0, int g, int max_ite
             SC_TRY(wait_test(k));  // the test of the previous iteration decides which codewords this pass may still write
             SC_TRY(launch_var(h, gs[k], st.post ? st.post + (size_t)ta * h->n * TW : nullptr, st.hard + (size_t)ta * h->n,
                               st.done + ta, skip, (early || last) ? 1 : 0, lane[k], t0[k],
-                              no_check ? st.synd + (size_t)ta * h->m : nullptr));
+                              no_check ? st.synd + (size_t)ta * h->m : nullptr, !no_check && rec_form(h, method)));
             if (ride && !last && !poll) {
                 verdict_pending[k] = true;  // the next check pass of this lane carries the test
             } else if ((early || last) && h->kn.fuse_finalize) {  // convergence test + latch, one launch
@@ -1172,7 +1239,7 @@ int decode_level(scaldpc_bp *h, int lvl, const TileState &st, int batch, int T, 
     if (el)
         SC_TRY(ensure_el(h, el));
     else
-        SC_TRY(ensure_msg(h, Gl));
+        SC_TRY(ensure_msg(h, Gl, method));
     if (lvl == 0) h->last_group = el ? 0 : Gl;
     if (el) h->stat_el = el;
     h->stat_levels = lvl;
@@ -1744,6 +1811,9 @@ int scaldpc_bp_append_rows(scaldpc_bp *h, int32_t nrows, const int32_t *row_ptr,
     dev_free(h->d_msg);
     dev_free(h->d_scratch);
     h->cap_group = 0;
+    dev_free(h->d_rec);
+    dev_free(h->d_mask);
+    h->cap_rec_group = 0;
     for (auto &L : h->lv) {
         dev_free(L.synd); dev_free(L.hard); dev_free(L.done); dev_free(L.conv); dev_free(L.unsat);
         dev_free(L.iters); dev_free(L.ids); dev_free(L.post);
@@ -2217,7 +2287,7 @@ int scaldpc_bp_time_kernels(scaldpc_bp *h, int32_t iters, int32_t method, float 
         for (int it = 0; it < iters && !rc; it++) rc = launch_check(h, method, alpha_for(alpha, it + 1), g, h->d_synd, h->d_done, 0, s);
         SC_HIP(hipEventRecord(ev[1], s));
         SC_HIP(hipEventRecord(ev[2], s));
-        for (int it = 0; it < iters && !rc; it++) rc = launch_var(h, g, nullptr, h->d_hard, h->d_done, 0, 0, s);
+        for (int it = 0; it < iters && !rc; it++) rc = launch_var(h, g, nullptr, h->d_hard, h->d_done, 0, 0, s, 0, nullptr, rec_form(h, method));
         SC_HIP(hipEventRecord(ev[3], s));
         if (!rc) SC_HIP(hipStreamSynchronize(s));
         if (!rc) {
@@ -2250,7 +2320,8 @@ int scaldpc_bp_time_kernels(scaldpc_bp *h, int32_t iters, int32_t method, float 
                 }
             }
             for (int k = 0; k < 2 && !rc; k++) {
-                rc = launch_var(h, gs[k], nullptr, h->d_hard + (size_t)t0[k] * h->n, h->d_done + t0[k], 0, 0, lane[k], t0[k]);
+                rc = launch_var(h, gs[k], nullptr, h->d_hard + (size_t)t0[k] * h->n, h->d_done + t0[k], 0, 0, lane[k], t0[k], nullptr,
+                                rec_form(h, method));
                 SC_HIP(hipEventRecord(M(k, 2 * it + 2), lane[k]));
             }
         }
@@ -2301,6 +2372,7 @@ void scaldpc_bp_destroy(scaldpc_bp *h)
     dev_free(h->d_first_tab);
     dev_free(h->d_el_tab);
     dev_free(h->d_msg); dev_free(h->d_scratch); dev_free(h->d_post);
+    dev_free(h->d_rec); dev_free(h->d_mask);
     dev_free(h->d_synd); dev_free(h->d_recv); dev_free(h->d_hard); dev_free(h->d_done);
     dev_free(h->d_conv); dev_free(h->d_unsat); dev_free(h->d_iters); dev_free(h->d_remaining);
     dev_free(h->d_in); dev_free(h->d_out_bits); dev_free(h->d_out_conv); dev_free(h->d_out_llr);

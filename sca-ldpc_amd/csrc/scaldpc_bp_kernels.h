@@ -622,6 +622,100 @@ __global__ __launch_bounds__(256) void k_check_minsum_x(const int *__restrict__ 
 }
 
 // ---------------------------------------------------------------------------
+// RECORD form of the min-sum check update (rows of degree <= 64).  A min-sum check sends only TWO magnitudes -- the
+// smallest incoming |x| to every edge but the arg-min, the second smallest to that one -- and a sign per edge.  Instead
+// of 4 B per edge and codeword (which the variable pass reads back as a gather), this pass leaves the message array
+// alone and writes, per (row, tile),
+//     rec  [tile][row][2][64]  float : m1 * alpha, m2 * alpha          (8 B per row and codeword)
+//     mask [tile][edge]        2 x u64 : lane masks "message negative", "this edge is the codeword's arg-min"
+//                                                                      (0.25 B per edge and codeword)
+// and the variable pass (k_var_rec) rebuilds every message from them: c2v = +-(arg-min ? rec[1] : rec[0]).  Since
+// m * (-alpha) == -(m * alpha) in IEEE arithmetic, that is the float k_check_minsum_x would have stored, bit for bit;
+// the sums that follow run in the same order, so nothing about parity changes -- only the bytes: the check pass
+// reads 4 B per edge and writes next to nothing, and the 2 MB of records per tile (HQC-128) are L2-sized.
+// Measured before it was built: profiles/microbench/minsum_records.hip.
+// ---------------------------------------------------------------------------
+template <int DEG, bool FIRST>
+__device__ __forceinline__ void check_minsum_row_rec(const float *p, unsigned par, float alpha, const float *__restrict__ prior,
+                                                     const int *__restrict__ cidx, float *__restrict__ rec,
+                                                     ulonglong2 *__restrict__ mask, int lane)
+{
+    float x[DEG];
+#pragma unroll
+    for (int k = 0; k < DEG; k++) x[k] = FIRST ? prior[rfl(cidx[k])] : p[(size_t)k * TW];
+    float m1 = FLT_MAX, m2 = FLT_MAX;
+    int ix = 0;
+#pragma unroll
+    for (int k = 0; k < DEG; k++) {
+        const float a = fabsf(x[k]);
+        par ^= (unsigned)(x[k] <= 0.0f);
+        const bool lt = a < m1;
+        m2 = lt ? m1 : ((a < m2) ? a : m2);
+        ix = lt ? k : ix;
+        m1 = lt ? a : m1;
+    }
+    rec[lane] = m1 * alpha;
+    rec[TW + lane] = m2 * alpha;
+    u64 mneg = 0, marg = 0;  // lane k keeps edge k's two masks
+#pragma unroll
+    for (int k = 0; k < DEG; k++) {
+        const u64 ng = __ballot((par ^ (unsigned)(x[k] <= 0.0f)) != 0);
+        const u64 ag = __ballot(ix == k);
+        if (lane == k) {
+            mneg = ng;
+            marg = ag;
+        }
+    }
+    if (lane < DEG) mask[lane] = make_ulonglong2(mneg, marg);
+}
+
+template <int CAP, bool FIRST, bool PAR = false>
+__global__ __launch_bounds__(256) void k_check_minsum_rec(const int *__restrict__ list, const float *msg,
+                                                          const u64 *__restrict__ synd, const u64 *done,
+                                                          int skip_done, int m, long E, float alpha,
+                                                          const int *__restrict__ col_idx, const float *__restrict__ prior,
+                                                          float *__restrict__ rec, ulonglong2 *__restrict__ mask,
+                                                          FusedTest ft = FusedTest{})
+{
+    const int lane = threadIdx.x & 63;
+    const int tl = blockIdx.y;
+    const int *md = list + (size_t)rfl((int)blockIdx.x * 4 + (int)(threadIdx.x >> 6)) * 4;  // uniform address: scalar loads
+    u64 dw = 0;
+    if constexpr (PAR) {
+        dw = done[tl];
+        if (skip_done && dw == ~0ull) return;
+    } else {
+        if (skip_done && done[tl] == ~0ull) return;
+    }
+    const int r = md[0];
+    u64 bad = 0;
+    if constexpr (PAR) bad = fused_row_parity(ft, tl, r, md[1], md[2], col_idx, synd, m);
+    if (!PAR && r < 0) return;
+    if (r >= 0) {
+        const int e0 = md[1];
+        const int deg = md[2];
+        const float *p = msg + ((size_t)tl * E + e0) * TW + lane;
+        float *rc = rec + ((size_t)tl * m + r) * 2 * TW;
+        ulonglong2 *mk = mask + (size_t)tl * E + e0;
+        const unsigned sbit = (unsigned)(synd[(size_t)tl * m + r] >> lane) & 1u;
+#define MR(D)                                                                                                       \
+    case D:                                                                                                         \
+        if constexpr (D <= CAP) check_minsum_row_rec<D, FIRST>(p, sbit, alpha, prior, col_idx + e0, rc, mk, lane);  \
+        break;
+#define MR8(D) MR(D) MR(D + 1) MR(D + 2) MR(D + 3) MR(D + 4) MR(D + 5) MR(D + 6) MR(D + 7)
+        switch (deg) {
+            MR(1) MR(2) MR(3) MR(4) MR(5) MR(6) MR(7)
+            MR8(8) MR8(16) MR8(24) MR8(32) MR8(40) MR8(48) MR8(56)
+            MR(64)
+            default: break;
+        }
+#undef MR8
+#undef MR
+    }
+    if constexpr (PAR) fused_commit(ft, tl, bad, dw);
+}
+
+// ---------------------------------------------------------------------------
 // K2  tanh-rule (sum-product) check-node update, LLR domain, fp32, COMPLEMENT form, in place.
 //   c2v_k = (-1)^(s + #{k' != k : x_k' < 0}) * 2 atanh( prod_{k' != k} tanh(|x_k'|/2) )
 // computed without the 1-x cancellation that saturates the textbook form at |L|~17
@@ -1245,6 +1339,127 @@ __global__ __launch_bounds__(256) void k_var_first(const int *__restrict__ list,
             if (lane == 0) hard[hi] = (hard[hi] & dn) | (hb & ~dn);
             if (post && !((dn >> lane) & 1)) post[hi * TW + lane] = L;
         }
+    }
+}
+
+// Variable pass of the min-sum RECORD form (see k_check_minsum_rec): the column's messages are rebuilt from the
+// records of its edges' rows.  Lane j fetches the j-th edge of the column and that edge's row (one round trip), then
+// the edge's two lane masks (a second one); edge k's triple reaches every lane through v_readlane, the record values
+// come as gathers with the row on the scalar side -- all of them issued before the first is used, the second
+// magnitude only for the lanes whose arg-min this edge is (one in `row degree` on average).
+//   csc_row: row of every position of the re-laid edge list (laid out like it)
+template <int MAXD>
+__device__ __forceinline__ float var_col_rec(float *tile_base, const float *__restrict__ rec_base, unsigned lane,
+                                             const int4 *__restrict__ rec4, const int *__restrict__ ce1, int rowv,
+                                             ulonglong2 mk, int d, float pr)
+{
+    int eid[MAXD];
+    {
+        const int4 a = rec4[1], b = rec4[2], c = rec4[3], e = rec4[4];
+        const int in16[16] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, c.x, c.y, c.z, c.w, e.x, e.y, e.z, e.w};
+#pragma unroll
+        for (int k = 0; k < MAXD && k < VAR_INLINE; k++) eid[k] = in16[k];
+#pragma unroll
+        for (int k = VAR_INLINE; k < MAXD; k++) eid[k] = ce1[k];
+    }
+    float mm[MAXD], pp[MAXD], m2[MAXD];
+    const int nlo = (int)(unsigned)mk.x, nhi = (int)(unsigned)(mk.x >> 32), alo = (int)(unsigned)mk.y, ahi = (int)(unsigned)(mk.y >> 32);
+    // three sweeps, so that every gather of the column is in flight before the first one is waited for: the first
+    // magnitudes, the second ones (only the lanes whose arg-min the edge is), then select + sign
+#pragma unroll
+    for (int k = 0; k < MAXD; k++)
+        if (k < d) mm[k] = (rec_base + (size_t)__builtin_amdgcn_readlane(rowv, k) * (2 * TW))[lane];
+#pragma unroll
+    for (int k = 0; k < MAXD; k++)
+        if (k < d) {
+            const u64 ag = ((u64)(unsigned)__builtin_amdgcn_readlane(ahi, k) << 32) | (unsigned)__builtin_amdgcn_readlane(alo, k);
+            m2[k] = 0.0f;
+            if ((ag >> lane) & 1) m2[k] = (rec_base + (size_t)__builtin_amdgcn_readlane(rowv, k) * (2 * TW) + TW)[lane];
+        }
+#pragma unroll
+    for (int k = 0; k < MAXD; k++)
+        if (k < d) {
+            const u64 ng = ((u64)(unsigned)__builtin_amdgcn_readlane(nhi, k) << 32) | (unsigned)__builtin_amdgcn_readlane(nlo, k);
+            const u64 ag = ((u64)(unsigned)__builtin_amdgcn_readlane(ahi, k) << 32) | (unsigned)__builtin_amdgcn_readlane(alo, k);
+            const float a = ((ag >> lane) & 1) ? m2[k] : mm[k];
+            mm[k] = __uint_as_float(__float_as_uint(a) ^ (((unsigned)(ng >> lane) & 1u) << 31));
+        }
+    float temp = pr;
+#pragma unroll
+    for (int k = 0; k < MAXD; k++)
+        if (k < d) {
+            pp[k] = temp;
+            temp += mm[k];
+        }
+    float suf = 0.0f;
+#pragma unroll
+    for (int k = MAXD - 1; k >= 0; k--)
+        if (k < d) {
+            (tile_base + (size_t)rfl(eid[k]) * TW)[lane] = pp[k] + suf;
+            suf += mm[k];
+        }
+    return temp;
+}
+
+// grid (bk.blk[nb], G), block 256 = 4 column records (k_var's launch shape and records).
+template <int CAP>
+__global__ __launch_bounds__(256) void k_var_rec(const int *__restrict__ list, const int *__restrict__ csc_edge,
+                                                 const int *__restrict__ csc_row, const float *__restrict__ prior, float *msg,
+                                                 const float *__restrict__ rec, const ulonglong2 *__restrict__ mask,
+                                                 float *__restrict__ post, u64 *__restrict__ hard, const u64 *__restrict__ done,
+                                                 int skip_done, int n, int m, long E, int write_out)
+{
+    const unsigned lane = threadIdx.x & 63u;
+    const int tl = blockIdx.y;
+    const int *rc = list + (size_t)rfl((int)blockIdx.x * 4 + (int)(threadIdx.x >> 6)) * VAR_REC;
+    const u64 dn = done[tl];
+    if (skip_done && dn == ~0ull) return;
+    const int v = rc[0];
+    if (v < 0) return;
+    const int cb = rc[1];
+    const int d = rc[2];
+    int ej = 0, rowv = 0;
+    if ((int)lane < d) {
+        ej = csc_edge[(size_t)cb + lane];
+        rowv = csc_row[(size_t)cb + lane];
+    }
+    ulonglong2 mk = make_ulonglong2(0, 0);
+    if ((int)lane < d) mk = mask[(size_t)tl * E + ej];
+    {
+        // ONE unconditional use of the loaded registers: the wait for the loads above then sits here.  Without it the
+        // first use is inside a block predicated on `k < d`, the skipped path has not waited, and the compiler guards
+        // every later predicated block with its own `s_waitcnt vmcnt(0)` -- in front of each gather, i.e. the gathers
+        // of a column run one after the other (measured: 80 us per launch against 64 for the message form).
+        unsigned a = (unsigned)mk.x, b = (unsigned)(mk.x >> 32), c = (unsigned)mk.y, e = (unsigned)(mk.y >> 32);
+        asm volatile("v_mov_b32 %0, %0\n\tv_mov_b32 %1, %1\n\tv_mov_b32 %2, %2\n\tv_mov_b32 %3, %3\n\tv_mov_b32 %4, %4"
+                     : "+v"(rowv), "+v"(a), "+v"(b), "+v"(c), "+v"(e));
+        mk = make_ulonglong2(((u64)b << 32) | a, ((u64)e << 32) | c);
+    }
+    float *tb = msg + (size_t)tl * E * TW;
+    const float *rb = rec + (size_t)tl * m * 2 * TW;
+    const int *ce = csc_edge + cb;
+    const int4 *r4 = (const int4 *)rc;
+    const float pr = prior[v];
+    float L = pr;
+    switch (rc[3]) {
+        case 1: L = var_col_rec<1>(tb, rb, lane, r4, ce, rowv, mk, d, pr); break;
+        case 2: L = var_col_rec<2>(tb, rb, lane, r4, ce, rowv, mk, d, pr); break;
+        case 4: L = var_col_rec<4>(tb, rb, lane, r4, ce, rowv, mk, d, pr); break;
+        case 8: L = var_col_rec<8>(tb, rb, lane, r4, ce, rowv, mk, d, pr); break;
+        case 16: L = var_col_rec<16>(tb, rb, lane, r4, ce, rowv, mk, d, pr); break;
+        case 32:
+            if constexpr (CAP >= 32) L = var_col_rec<32>(tb, rb, lane, r4, ce, rowv, mk, d, pr);
+            break;
+        case 64:
+            if constexpr (CAP >= 64) L = var_col_rec<64>(tb, rb, lane, r4, ce, rowv, mk, d, pr);
+            break;
+        default: break;  // (no any-degree columns when this kernel is launched)
+    }
+    if (write_out) {
+        const u64 hb = __ballot(L <= 0.0f);
+        const size_t hi = (size_t)tl * n + v;
+        if (lane == 0) hard[hi] = (hard[hi] & dn) | (hb & ~dn);
+        if (post && !((dn >> lane) & 1)) post[hi * TW + lane] = L;
     }
 }
 
