@@ -237,7 +237,10 @@ def main():
         value = updates / dt
         check_gbs = 8.0 * E * swept / (ms_check * 1e-3) / 1e9  # 4 B read + 4 B written per edge per codeword
         var_gbs = 8.0 * E * kt["codewords_var"] / (ms_var_pass * 1e-3) / 1e9
-        cname = "k_check_minsum_x" if method == "min_sum" else "k_check_tanh"
+        rec = bool(kt.get("record_form"))  # min-sum in its record form (knob minsum_rec): other kernels, same algorithmic bytes
+        cname = ("k_check_minsum_rec" if rec else "k_check_minsum_x") if method == "min_sum" else "k_check_tanh"
+        vname = "k_var_rec" if rec else "k_var"
+        cpmc = ("k_check_minsum_rec" if rec else "k_check_minsum") if method == "min_sum" else "k_check_tanh"
         out = {
             "metric": "edge_message_updates_per_s",
             "value": value,
@@ -281,15 +284,15 @@ def main():
         # (`hbm_copy_ceiling_GBps`, `hbm_streaming_GBps`); `peak` stays the HBM datasheet figure the
         # contract names.
         dom_is_var = ms_var_pass >= ms_check
-        dname = "k_var" if dom_is_var else cname
+        dname = vname if dom_is_var else cname
         achieved = lanes * (8.0 * E * swept + 8.0 * E * kt["codewords_var"]) / ((ms_check + ms_var_pass) * 1e-3) / 1e9
         traffic, traffic_src = None, None
         if live_traffic and live_traffic.get("codewords_per_launch") == swept:
-            tk = live_traffic["kernels"].get("k_var" if dom_is_var else ("k_check_minsum" if method == "min_sum" else "k_check_tanh"))
+            tk = live_traffic["kernels"].get(vname if dom_is_var else cpmc)
             if tk:
                 traffic, traffic_src = tk["traffic_bytes"], "live rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this run"
         if traffic is None and args.pmc != "off":
-            traffic = pmc_traffic(args.workload, batch, swept, "k_var" if dom_is_var else ("k_check_minsum" if method == "min_sum" else "k_check_tanh"))
+            traffic = pmc_traffic(args.workload, batch, swept, vname if dom_is_var else cpmc)
             traffic_src = "profiles/ (committed PMC passes of this geometry)" if traffic is not None else None
         out["roofline"] = {
             "bound": "infinity-cache",  # what serves the bytes; the contract's class for this path is "hbm" (no MFMA)
@@ -310,7 +313,7 @@ def main():
                          "frac": (var_gbs if dom_is_var else check_gbs) / HBM_PEAK_GBS if lanes == 1 else None},
             "per_launch": {
                 cname: {"codewords": swept, "us": ms_check * 1e3, "algorithmic_GBps": check_gbs},
-                "k_var": {"codewords": kt["codewords_var"], "us": ms_var_pass * 1e3, "algorithmic_GBps": var_gbs},
+                vname: {"codewords": kt["codewords_var"], "us": ms_var_pass * 1e3, "algorithmic_GBps": var_gbs},
             },
             "hbm_streaming_GBps": hbm_stream["GBps"] if hbm_stream else None,
             "hbm_streaming": hbm_stream,
@@ -320,15 +323,21 @@ def main():
             "frac_is": "algorithmic bytes of the cache-resident schedule / HBM datasheet peak (served by the Infinity Cache)",
             "hbm_frac": hbm_stream["GBps"] / HBM_PEAK_GBS if hbm_stream else None,
         }
+        if rec:
+            out["roofline"]["scheme"] = (
+                "min-sum record form: `achieved` / `frac` keep SURVEY 8(d)'s ALGORITHMIC figure (two fp32 message arrays, 16 B per "
+                "edge, codeword and iteration), as the survey prescribes for an implementation that moves fewer real bytes; what the "
+                "kernels really move per codeword and iteration is 4E read + 8m + E/4 written (check) and 4E written + E/4 + the "
+                "row records (8m, re-read from L2 for every edge) read (variable): about 8.7E through the fabric")
         if live_traffic:
             out["roofline"]["traffic_all_kernels"] = live_traffic["kernels"]
         if iso:
             ic = iso["ms_check"] / max(1, iso["launches_check"])
             iv = iso["ms_var"] / max(1, iso["launches_var"])
-            ig = {cname: 8.0 * E * iso["codewords"] / (ic * 1e-3) / 1e9, "k_var": 8.0 * E * iso["codewords_var"] / (iv * 1e-3) / 1e9}
+            ig = {cname: 8.0 * E * iso["codewords"] / (ic * 1e-3) / 1e9, vname: 8.0 * E * iso["codewords_var"] / (iv * 1e-3) / 1e9}
             out["roofline"]["isolated"] = {
                 cname: {"codewords": iso["codewords"], "us": ic * 1e3, "algorithmic_GBps": ig[cname]},
-                "k_var": {"codewords": iso["codewords_var"], "us": iv * 1e3, "algorithmic_GBps": ig["k_var"]},
+                vname: {"codewords": iso["codewords_var"], "us": iv * 1e3, "algorithmic_GBps": ig[vname]},
             }
             out["roofline"]["dominant"]["frac"] = ig[dname] / HBM_PEAK_GBS  # the dominant kernel alone on the chip
         if args.parity_rows > 0:
@@ -417,7 +426,7 @@ def pmc_live(workload):
                     if row["Counter_Name"] != counter:
                         continue
                     name = re.sub(r"^void ", "", row["Kernel_Name"].replace("(anonymous namespace)::", "")).split("(")[0]
-                    if not name.startswith(("k_var", "k_check")) or name.endswith("true>"):
+                    if not name.startswith(("k_var", "k_check")) or re.search(r"^k_check[^<]*<[^,>]+, true", name):
                         continue  # (FIRST = true: the first iteration reads the priors, not the messages)
                     base = name.split("<")[0]
                     key = (base[:-2] if base.endswith("_x") else base, row["Grid_Size"])
@@ -858,7 +867,7 @@ def pmc_traffic(workload, batch, swept, kernel):
             d = json.load(open(path))
             if d["batch"] == batch and d["tile_group_codewords"] == swept:
                 for name, v in d["kernels"].items():  # name prefix; the steady-state instantiation (FIRST = false)
-                    if name.startswith(kernel) and not name.endswith("true>"):
+                    if name.startswith(kernel) and not re.search(r"^k_check[^<]*<[^,>]+, true", name):
                         return v["traffic_bytes"]
         except Exception:
             pass

@@ -153,7 +153,8 @@ int scaldpc_bp_decode_batch(scaldpc_bp *h, const uint8_t *in, int32_t input_kind
  *                   2 = the decode's two-stream schedule: the check series over the first
  *                   lane's tiles and the variable series over the second lane's tiles ran
  *                   concurrently, as they do in a decode's steady state
- *   launches[4]     codewords swept per variable launch;  launches[5] reserved (0)
+ *   launches[4]     codewords swept per variable launch;  launches[5] = 1 if min-sum ran in
+ *                   its record form (k_check_minsum_rec / k_var_rec; knob "minsum_rec"), else 0
  */
 int scaldpc_bp_time_kernels(scaldpc_bp *h, int32_t iters, int32_t method, float alpha, void *stream,
                             float *ms, int32_t *launches);
@@ -201,6 +202,10 @@ int scaldpc_bp_last_stats(scaldpc_bp *h, int64_t *out);
  *   "fuse_test"     1 (default) = in the early-exit tile loop the convergence test of an iteration rides on the check
  *                   pass of the next one (except where the host polls or stops), with sharded accumulators;
  *                   0 = a stand-alone launch after every variable pass (SCALDPC_FUSE_TEST).
+ *   "minsum_rec"    1 (default) = min-sum on the 64-codeword-tile kernels in its RECORD form: the check pass writes, per
+ *                   row and codeword, the two magnitudes a min-sum check sends (8 B) and, per edge and tile, two lane
+ *                   masks (sign, arg-min: 0.25 B per codeword) instead of 4 B per edge and codeword; the variable pass
+ *                   rebuilds every message from them, bit for bit.  0 = messages both ways.  (SCALDPC_MINSUM_REC)
  *   "first_fused"   1 (default) = iteration 1 of the tile kernels runs without its check pass: the first variable
  *                   pass takes the first check-to-variable messages from a per-edge table (the message of a
  *                   zero-syndrome codeword) and the row's syndrome bit; 0 = check pass + plain variable pass

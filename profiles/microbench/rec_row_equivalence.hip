@@ -1,0 +1,149 @@
+// standalone comparison of the two row updates of k_check_minsum_rec (old: compare-select + per-lane state; new: scalar masks)
+#include <hip/hip_runtime.h>
+#include <cfloat>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+typedef unsigned long long u64;
+constexpr int TW = 64;
+__device__ __forceinline__ int rfl(int x) { return __builtin_amdgcn_readfirstlane(x); }
+template <int DEG, bool FIRST>
+__device__ __forceinline__ void row_old(const float *p, u64 synd_mask, float alpha, const float *__restrict__ prior,
+                                                     const int *__restrict__ cidx, float *__restrict__ rec,
+                                                     float *__restrict__ rec2, ulonglong2 *__restrict__ mask, int lane)
+{
+    unsigned par = (unsigned)(synd_mask >> lane) & 1u;
+    float x[DEG];
+#pragma unroll
+    for (int k = 0; k < DEG; k++) x[k] = FIRST ? prior[rfl(cidx[k])] : p[(size_t)k * TW];
+    float m1 = FLT_MAX, m2 = FLT_MAX;
+    int ix = 0;
+#pragma unroll
+    for (int k = 0; k < DEG; k++) {
+        const float a = fabsf(x[k]);
+        par ^= (unsigned)(x[k] <= 0.0f);
+        const bool lt = a < m1;
+        m2 = lt ? m1 : ((a < m2) ? a : m2);
+        ix = lt ? k : ix;
+        m1 = lt ? a : m1;
+    }
+    rec[lane] = m1 * alpha;
+    rec2[lane] = m2 * alpha;
+    u64 mneg = 0, marg = 0;  // lane k keeps edge k's two masks
+#pragma unroll
+    for (int k = 0; k < DEG; k++) {
+        const u64 ng = __ballot((par ^ (unsigned)(x[k] <= 0.0f)) != 0);
+        const u64 ag = __ballot(ix == k);
+        if (lane == k) {
+            mneg = ng;
+            marg = ag;
+        }
+    }
+    if (lane < DEG) mask[lane] = make_ulonglong2(mneg, marg);
+}
+
+template <int DEG, bool FIRST>
+__device__ __forceinline__ void row_new(const float *p, u64 synd_mask, float alpha, const float *__restrict__ prior,
+                                                     const int *__restrict__ cidx, float *__restrict__ rec,
+                                                     float *__restrict__ rec2, ulonglong2 *__restrict__ mask, int lane)
+{
+    float x[DEG];
+#pragma unroll
+    for (int k = 0; k < DEG; k++) x[k] = FIRST ? prior[rfl(cidx[k])] : p[(size_t)k * TW];
+    float m1 = FLT_MAX, m2 = FLT_MAX;
+    const float fmax = FLT_MAX;
+    u64 par = ((u64)(unsigned)rfl((int)(synd_mask >> 32)) << 32) | (unsigned)rfl((int)synd_mask);  // (uniform by construction: keep it on the scalar side)
+#pragma unroll
+    for (int k = 0; k < DEG; k++) {
+        par ^= __ballot(x[k] <= 0.0f);
+        float a;
+        asm("v_min_f32 %0, |%1|, %2" : "=v"(a) : "v"(x[k]), "v"(fmax));
+        asm("v_med3_f32 %0, %1, %2, %0" : "+v"(m2) : "v"(a), "v"(m1));
+        asm("v_min_f32 %0, %0, %1" : "+v"(m1) : "v"(a));
+    }
+    rec[lane] = m1 * alpha;
+    rec2[lane] = m2 * alpha;
+    unsigned nlo = 0, nhi = 0, alo = 0, ahi = 0;  // lane k keeps edge k's two masks
+    // `found` starts as a zero the compiler cannot see through: every mask that reaches a v_writelane below is then the
+    // result of a SCALAR instruction (s_xor / s_andn2).  A v_writelane in inline asm that reads an SGPR the v_cmp right
+    // in front of it has just written gets the OLD value on gfx950 (the compiler's hazard recogniser pads its own
+    // instructions, not the inside of an asm statement): measured with edge 0's arg-min mask of degree-1 rows
+    // (profiles/microbench/rec_row_equivalence.hip).
+    u64 found;
+    asm volatile("s_mov_b64 %0, 0" : "=s"(found));
+#pragma unroll
+    for (int k = 0; k < DEG; k++) {
+        const u64 ng = __ballot(x[k] <= 0.0f) ^ par;
+        const u64 eq = __ballot(fabsf(x[k]) == m1);
+        const u64 ag = eq & ~found;
+        found |= eq;
+        asm("v_writelane_b32 %0, %1, %2" : "+v"(nlo) : "s"((unsigned)ng), "n"(k));
+        asm("v_writelane_b32 %0, %1, %2" : "+v"(nhi) : "s"((unsigned)(ng >> 32)), "n"(k));
+        asm("v_writelane_b32 %0, %1, %2" : "+v"(alo) : "s"((unsigned)ag), "n"(k));
+        asm("v_writelane_b32 %0, %1, %2" : "+v"(ahi) : "s"((unsigned)(ag >> 32)), "n"(k));
+    }
+    if (lane < DEG) mask[lane] = make_ulonglong2(((u64)nhi << 32) | nlo, ((u64)ahi << 32) | alo);
+}
+
+
+template <int DEG>
+__global__ void k(const float *msg, const u64 *synd, float alpha, float *recA, float *rec2A, ulonglong2 *maskA, float *recB, float *rec2B, ulonglong2 *maskB)
+{
+    const int lane = threadIdx.x, r = blockIdx.x;
+    const float *p = msg + (size_t)r * DEG * TW + lane;
+    row_old<DEG, false>(p, synd[r], alpha, nullptr, nullptr, recA + r * TW, rec2A + r * TW, maskA + r * DEG, lane);
+    row_new<DEG, false>(p, synd[r], alpha, nullptr, nullptr, recB + r * TW, rec2B + r * TW, maskB + r * DEG, lane);
+}
+template <int DEG>
+int run(int rows, unsigned seed)
+{
+    srand(seed);
+    std::vector<float> h((size_t)rows * DEG * TW);
+    for (auto &v : h) {
+        int t = rand() % 11;
+        v = (float)(rand() % 7 - 3) * 0.5f;  // few distinct magnitudes: ties, zeros, negative zeros
+        if (t == 0) v = -0.0f;
+        if (t == 1) v = INFINITY;
+        if (t == 2) v = -INFINITY;
+        if (t == 3) v = NAN;
+        if (t == 4) v = FLT_MAX;
+    }
+    std::vector<u64> sy(rows);
+    for (auto &v : sy) v = ((u64)rand() << 40) ^ ((u64)rand() << 20) ^ rand();
+    float *d, *ra, *r2a, *rb, *r2b; u64 *ds; ulonglong2 *ma, *mb;
+    hipMalloc(&d, h.size() * 4); hipMalloc(&ds, rows * 8);
+    hipMalloc(&ra, rows * TW * 4); hipMalloc(&r2a, rows * TW * 4); hipMalloc(&rb, rows * TW * 4); hipMalloc(&r2b, rows * TW * 4);
+    hipMalloc(&ma, rows * DEG * 16); hipMalloc(&mb, rows * DEG * 16);
+    hipMemcpy(d, h.data(), h.size() * 4, hipMemcpyHostToDevice); hipMemcpy(ds, sy.data(), rows * 8, hipMemcpyHostToDevice);
+    hipLaunchKernelGGL(k<DEG>, dim3(rows), dim3(64), 0, 0, d, ds, 0.75f, ra, r2a, ma, rb, r2b, mb);
+    hipDeviceSynchronize();
+    std::vector<float> A(rows * TW), A2(rows * TW), B(rows * TW), B2(rows * TW);
+    std::vector<u64> MA(rows * DEG * 2), MB(rows * DEG * 2);
+    hipMemcpy(A.data(), ra, A.size() * 4, hipMemcpyDeviceToHost); hipMemcpy(A2.data(), r2a, A.size() * 4, hipMemcpyDeviceToHost);
+    hipMemcpy(B.data(), rb, A.size() * 4, hipMemcpyDeviceToHost); hipMemcpy(B2.data(), r2b, A.size() * 4, hipMemcpyDeviceToHost);
+    hipMemcpy(MA.data(), ma, MA.size() * 8, hipMemcpyDeviceToHost); hipMemcpy(MB.data(), mb, MB.size() * 8, hipMemcpyDeviceToHost);
+    // compare the MESSAGES the variable pass would rebuild (an arg-min flag on another edge of the same magnitude is the same message)
+    long bad = 0, badrec = 0, badneg = 0;
+    for (int r = 0; r < rows; r++)
+        for (int l = 0; l < TW; l++) {
+            if (memcmp(&A[r * TW + l], &B[r * TW + l], 4) || memcmp(&A2[r * TW + l], &B2[r * TW + l], 4)) badrec++;
+            for (int e = 0; e < DEG; e++) {
+                const u64 na = MA[(r * DEG + e) * 2], aa = MA[(r * DEG + e) * 2 + 1], nb = MB[(r * DEG + e) * 2], ab = MB[(r * DEG + e) * 2 + 1];
+                float va = ((aa >> l) & 1) ? A2[r * TW + l] : A[r * TW + l], vb = ((ab >> l) & 1) ? B2[r * TW + l] : B[r * TW + l];
+                if (((na >> l) & 1) != ((nb >> l) & 1)) badneg++;
+                if ((na >> l) & 1) va = -va;
+                if ((nb >> l) & 1) vb = -vb;
+                if (memcmp(&va, &vb, 4)) { if (bad < 6) printf("  row %d lane %d edge %d: x=%g old: m1a=%g m2a=%g neg=%d arg=%d | new: m1a=%g m2a=%g neg=%d arg=%d\n", r, l, e, h[((size_t)r * DEG + e) * TW + l], A[r*TW+l], A2[r*TW+l], (int)((na>>l)&1), (int)((aa>>l)&1), B[r*TW+l], B2[r*TW+l], (int)((nb>>l)&1), (int)((ab>>l)&1)); bad++; }
+            }
+        }
+    printf("DEG %2d: %ld of %d messages differ, %ld records, %ld signs\n", DEG, bad, rows * TW * DEG, badrec, badneg);
+    return bad != 0;
+}
+int main()
+{
+    int rc = 0;
+    rc |= run<1>(64, 1); rc |= run<2>(64, 2); rc |= run<3>(64, 3); rc |= run<4>(64, 4); rc |= run<5>(64, 5); rc |= run<7>(64, 6);
+    rc |= run<9>(64, 7); rc |= run<13>(64, 8); rc |= run<16>(64, 9); rc |= run<33>(64, 10); rc |= run<51>(64, 11); rc |= run<64>(64, 12);
+    return rc;
+}

@@ -21,7 +21,7 @@ def main():
     tot, cnt = defaultdict(lambda: defaultdict(float)), defaultdict(lambda: defaultdict(int))
     for r in csv.DictReader(open(src)):
         name = re.sub(r"^void ", "", r["Kernel_Name"].replace("(anonymous namespace)::", "")).split("(")[0]
-        if not name.startswith(prefixes) or name.endswith("true>"):
+        if not name.startswith(prefixes) or re.search(r"^k_check[^<]*<[^,>]+, true", name):
             continue
         key = (name, r["Grid_Size"])
         tot[key][r["Counter_Name"]] += float(r["Counter_Value"])

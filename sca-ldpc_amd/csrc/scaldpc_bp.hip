@@ -77,6 +77,7 @@ struct Knobs {
     int first_fused = 1;      // iteration 1 of the tile kernels without its check pass (k_var_first from the first-message table); 0 = check pass + plain variable pass
     int test_overlap = 0;     // early-exit tile groups: 1 = the convergence test of iteration it runs on a side stream beside the check pass of it + 1 (A/B knob: measured 3.4 % SLOWER on the config-5 sweep, profiles/r03/ab_test_overlap.log)
     int var_form = 1;         // k_var: 0 = ids fetched edge by edge, 1 = all ids up front as wide scalar loads (default)
+    int rec_sc1 = 1;          // record form: message stores of the variable pass leave the XCD's L2 (sc1); 0 = plain stores (A/B knob)
     int minsum_rec = 1;       // min-sum on the tile kernels: check pass writes per-row records + lane masks instead of messages (k_check_minsum_rec / k_var_rec); 0 = message form
 };
 
@@ -179,7 +180,7 @@ struct scaldpc_bp {
     float *d_rec = nullptr;
     ulonglong2 *d_mask = nullptr;
     int cap_rec_group = 0;
-    int *d_csc_row = nullptr;
+    int *d_csc_row = nullptr, *d_var_rows = nullptr;
     bool first_valid = false;
     int first_method = -1;
     float first_alpha = 0.0f;
@@ -235,6 +236,7 @@ bool set_knob(Knobs &k, const char *key, const char *val)
     else if (!strcmp(key, "test_overlap")) k.test_overlap = (int)x != 0;
     else if (!strcmp(key, "first_fused")) k.first_fused = (int)x != 0;
     else if (!strcmp(key, "minsum_rec")) k.minsum_rec = (int)x != 0;
+    else if (!strcmp(key, "rec_sc1")) k.rec_sc1 = (int)x != 0;
     else if (!strcmp(key, "fuse_test")) k.fuse_test = (int)x != 0;
     else return false;
     return true;
@@ -245,7 +247,7 @@ void knobs_from_env(Knobs &k)
     static const char *const names[][2] = {{"SCALDPC_PATH", "path"}, {"SCALDPC_SPLIT", "split"},
                                            {"SCALDPC_GROUP_MB", "group_mb"}, {"SCALDPC_EL_MAX", "el_max"},
                                            {"SCALDPC_EL_FUSE", "el_fuse"}, {"SCALDPC_COMPACT_AFTER", "compact_after"},
-                                           {"SCALDPC_VAR_ORDER", "var_order"}, {"SCALDPC_VAR_FORM", "var_form"}, {"SCALDPC_SPECULATE", "speculate"}, {"SCALDPC_FUSE_FINALIZE", "fuse_finalize"}, {"SCALDPC_TEST_OVERLAP", "test_overlap"}, {"SCALDPC_FIRST_FUSED", "first_fused"}, {"SCALDPC_FUSE_TEST", "fuse_test"}, {"SCALDPC_MINSUM_REC", "minsum_rec"}};
+                                           {"SCALDPC_VAR_ORDER", "var_order"}, {"SCALDPC_VAR_FORM", "var_form"}, {"SCALDPC_SPECULATE", "speculate"}, {"SCALDPC_FUSE_FINALIZE", "fuse_finalize"}, {"SCALDPC_TEST_OVERLAP", "test_overlap"}, {"SCALDPC_FIRST_FUSED", "first_fused"}, {"SCALDPC_FUSE_TEST", "fuse_test"}, {"SCALDPC_MINSUM_REC", "minsum_rec"}, {"SCALDPC_REC_SC1", "rec_sc1"}};
     for (auto &nm : names)
         if (const char *e = getenv(nm[0])) (void)set_knob(k, nm[1], e);
     if (getenv("SCALDPC_MINSUM_LOOP")) k.minsum_loop = 1;  // presence switches it on, as before
@@ -412,6 +414,7 @@ int ensure_tile_tables(scaldpc_bp *h)
     const size_t o_var_meta = reserve((size_t)4 * VAR_REC * hv.bk.blk[hv.bk.nb] + 4), o_csc_list = reserve((size_t)h->E + 1 + 64);
     const size_t o_row_list = reserve((size_t)16 * hr.bk.blk[hr.bk.nb] + 4);
     const size_t o_csc_row = reserve((size_t)h->E + 1 + 64);
+    const size_t o_var_rows = reserve((size_t)4 * VAR_INLINE * hv.bk.blk[hv.bk.nb] + 4);  // rows of the records' inline edges
     int *host = stage_buffer(total);
     if (!host) return fail(SCALDPC_ENOMEM, "out of host memory");
     for (int b = 0; b < hr.bk.nb; b++) {
@@ -461,9 +464,11 @@ int ensure_tile_tables(scaldpc_bp *h)
         const int blocks = hv.bk.blk[b + 1] - hv.bk.blk[b];
         for (int sl = 0; sl < blocks * 4; sl++) {
             int *md = meta + (size_t)VAR_REC * ((size_t)hv.bk.blk[b] * 4 + sl);
+            int *mr = host + o_var_rows + (size_t)VAR_INLINE * ((size_t)hv.bk.blk[b] * 4 + sl);
             if (sl >= hv.bk.cnt[b]) {
                 md[0] = -1;
                 for (int k = 1; k < VAR_REC; k++) md[k] = 0;
+                for (int k = 0; k < VAR_INLINE; k++) mr[k] = 0;
                 continue;
             }
             const int v = vlist[hv.bk.off[b] + sl], d = cdeg[v];
@@ -476,6 +481,7 @@ int ensure_tile_tables(scaldpc_bp *h)
                 relaid_row[pos + k] = edge_row[relaid[pos + k]];
             }
             for (int k = 0; k < VAR_INLINE; k++) md[4 + k] = k < d ? relaid[pos + k] : 0;
+            for (int k = 0; k < VAR_INLINE; k++) mr[k] = k < d ? relaid_row[pos + k] : 0;
             pos += d;
         }
     }
@@ -483,8 +489,11 @@ int ensure_tile_tables(scaldpc_bp *h)
         // heaviest columns FIRST: the waves that start last are then the cheapest ones (degree-1 identity
         // columns), which shortens the tail of the launch (longest-processing-time-first)
         const size_t nrec = (size_t)4 * hv.bk.blk[hv.bk.nb];
-        for (size_t i = 0, j = nrec ? nrec - 1 : 0; i < j; i++, j--)
+        int *rows = host + o_var_rows;
+        for (size_t i = 0, j = nrec ? nrec - 1 : 0; i < j; i++, j--) {
             std::swap_ranges(meta + i * VAR_REC, meta + (i + 1) * VAR_REC, meta + j * VAR_REC);
+            std::swap_ranges(rows + i * VAR_INLINE, rows + (i + 1) * VAR_INLINE, rows + j * VAR_INLINE);
+        }
     }
     SC_TRY(upload_table(&h->d_tile_tab, host, total));
     h->first_valid = false;  // (first_tab follows the re-laid edge list)
@@ -492,6 +501,7 @@ int ensure_tile_tables(scaldpc_bp *h)
     h->d_csc_list = h->d_tile_tab + o_csc_list;
     h->d_row_list = h->d_tile_tab + o_row_list;
     h->d_csc_row = h->d_tile_tab + o_csc_row;
+    h->d_var_rows = h->d_tile_tab + o_var_rows;
     return 0;
 }
 
@@ -819,16 +829,15 @@ int launch_var(scaldpc_bp *h, int G, float *post_g, u64 *hard_g, const u64 *done
         return 0;
     }
     if (rec) {  // the check pass left records, not messages (rec_form)
-#define VAR_REC_LAUNCH(CAP)                                                                                         \
-    hipLaunchKernelGGL((k_var_rec<CAP>), grid, dim3(256), 0, s, h->d_var_meta, h->d_csc_list, h->d_csc_row, h->d_prior, msg0, \
-                       h->d_rec + (size_t)tile0 * h->m * 2 * TW, h->d_mask + (size_t)tile0 * h->E, post_g, hard_g, done_g,   \
-                       skip_done, h->n, h->m, h->E, write_out)
-        if (h->max_col_deg <= 16)
-            VAR_REC_LAUNCH(16);
-        else if (h->max_col_deg <= 32)
-            VAR_REC_LAUNCH(32);
-        else
-            VAR_REC_LAUNCH(64);
+#define VAR_REC_LAUNCH(CAP, S1)                                                                                     \
+    hipLaunchKernelGGL((k_var_rec<CAP, S1>), grid, dim3(256), 0, s, h->d_var_meta, h->d_var_rows, h->d_csc_list, h->d_csc_row, \
+                       h->d_prior, msg0, h->d_rec + (size_t)tile0 * h->m * 2 * TW, h->d_mask + (size_t)tile0 * h->E, post_g,  \
+                       hard_g, done_g, skip_done, h->n, h->m, h->E, write_out)
+        if (h->kn.rec_sc1) {
+            if (h->max_col_deg <= 16) VAR_REC_LAUNCH(16, true); else if (h->max_col_deg <= 32) VAR_REC_LAUNCH(32, true); else VAR_REC_LAUNCH(64, true);
+        } else {
+            if (h->max_col_deg <= 16) VAR_REC_LAUNCH(16, false); else if (h->max_col_deg <= 32) VAR_REC_LAUNCH(32, false); else VAR_REC_LAUNCH(64, false);
+        }
 #undef VAR_REC_LAUNCH
         LAUNCH_CHECK();
         return 0;
@@ -2296,7 +2305,7 @@ int scaldpc_bp_time_kernels(scaldpc_bp *h, int32_t iters, int32_t method, float 
             launches[0] = launches[1] = iters;
             launches[2] = launches[4] = g * TW;  // codewords swept per launch
             launches[3] = 1;
-            launches[5] = 0;
+            launches[5] = rec_form(h, method) ? 1 : 0;
         }
     } else {
         SC_TRY(ensure_lanes(h, 2));
@@ -2348,7 +2357,7 @@ int scaldpc_bp_time_kernels(scaldpc_bp *h, int32_t iters, int32_t method, float 
             launches[2] = gs[0] * TW;
             launches[4] = gs[0] * TW;  // (odd groups: the second lane's launches are one tile smaller)
             launches[3] = 2;
-            launches[5] = 0;
+            launches[5] = rec_form(h, method) ? 1 : 0;
         }
         for (auto &e : mark) (void)hipEventDestroy(e);
     }

@@ -626,7 +626,9 @@ __global__ __launch_bounds__(256) void k_check_minsum_x(const int *__restrict__ 
 // smallest incoming |x| to every edge but the arg-min, the second smallest to that one -- and a sign per edge.  Instead
 // of 4 B per edge and codeword (which the variable pass reads back as a gather), this pass leaves the message array
 // alone and writes, per (row, tile),
-//     rec  [tile][row][2][64]  float : m1 * alpha, m2 * alpha          (8 B per row and codeword)
+//     rec  [tile][2][row][64]  float : m1 * alpha | m2 * alpha         (8 B per row and codeword; two dense planes per
+//                                      tile: interleaved by row, the always-read first magnitudes would sit at a
+//                                      512-B stride, i.e. in half of the L2's sets and channels)
 //     mask [tile][edge]        2 x u64 : lane masks "message negative", "this edge is the codeword's arg-min"
 //                                                                      (0.25 B per edge and codeword)
 // and the variable pass (k_var_rec) rebuilds every message from them: c2v = +-(arg-min ? rec[1] : rec[0]).  Since
@@ -635,38 +637,59 @@ __global__ __launch_bounds__(256) void k_check_minsum_x(const int *__restrict__ 
 // reads 4 B per edge and writes next to nothing, and the 2 MB of records per tile (HQC-128) are L2-sized.
 // Measured before it was built: profiles/microbench/minsum_records.hip.
 // ---------------------------------------------------------------------------
+// The row update is written for VALU issue, which is what bounds the record-form kernels once the bytes are gone (a
+// wave64 instruction holds its SIMD for 4 cycles; the first version spent 25 instructions per edge here, 1274 per row
+// of the HQC-128 graph).  Per-lane state is only the two minima; everything that is one bit per codeword lives in
+// 64-bit SCALAR lane masks and is combined on the scalar unit:
+//   sweep 1, per edge: negative? -> v_cmp into a mask, parity ^= mask (scalar); |x| clamped to FLT_MAX (v_min: a NaN
+//            or infinite input never wins a strict compare against minima that start at FLT_MAX, so the clamp changes
+//            nothing the loop form computes), m2 = med3(a, m1, m2), m1 = min(m1, a)  -- the compare-select recurrences
+//            of k_check_minsum_x, value for value (a < m1: m2 takes the old m1; m1 <= a < m2: m2 takes a; else nothing);
+//   sweep 2, per edge: negative? again (the inputs are still in registers), |x| == m1 -> mask; the arg-min is the FIRST
+//            edge that attains m1, as `ix` was: arg = eq & ~found, found |= eq (scalar); sign = negative ^ parity
+//            (scalar); the two masks go into lane k of the output registers with v_writelane.
+// 10 VALU instructions per edge.
 template <int DEG, bool FIRST>
-__device__ __forceinline__ void check_minsum_row_rec(const float *p, unsigned par, float alpha, const float *__restrict__ prior,
+__device__ __forceinline__ void check_minsum_row_rec(const float *p, u64 synd_mask, float alpha, const float *__restrict__ prior,
                                                      const int *__restrict__ cidx, float *__restrict__ rec,
-                                                     ulonglong2 *__restrict__ mask, int lane)
+                                                     float *__restrict__ rec2, ulonglong2 *__restrict__ mask, int lane)
 {
     float x[DEG];
 #pragma unroll
     for (int k = 0; k < DEG; k++) x[k] = FIRST ? prior[rfl(cidx[k])] : p[(size_t)k * TW];
     float m1 = FLT_MAX, m2 = FLT_MAX;
-    int ix = 0;
+    const float fmax = FLT_MAX;
+    u64 par = ((u64)(unsigned)rfl((int)(synd_mask >> 32)) << 32) | (unsigned)rfl((int)synd_mask);  // (uniform by construction: keep it on the scalar side)
 #pragma unroll
     for (int k = 0; k < DEG; k++) {
-        const float a = fabsf(x[k]);
-        par ^= (unsigned)(x[k] <= 0.0f);
-        const bool lt = a < m1;
-        m2 = lt ? m1 : ((a < m2) ? a : m2);
-        ix = lt ? k : ix;
-        m1 = lt ? a : m1;
+        par ^= __ballot(x[k] <= 0.0f);
+        float a;
+        asm("v_min_f32 %0, |%1|, %2" : "=v"(a) : "v"(x[k]), "v"(fmax));
+        asm("v_med3_f32 %0, %1, %2, %0" : "+v"(m2) : "v"(a), "v"(m1));
+        asm("v_min_f32 %0, %0, %1" : "+v"(m1) : "v"(a));
     }
     rec[lane] = m1 * alpha;
-    rec[TW + lane] = m2 * alpha;
-    u64 mneg = 0, marg = 0;  // lane k keeps edge k's two masks
+    rec2[lane] = m2 * alpha;
+    unsigned nlo = 0, nhi = 0, alo = 0, ahi = 0;  // lane k keeps edge k's two masks
+    // `found` starts as a zero the compiler cannot see through: every mask that reaches a v_writelane below is then the
+    // result of a SCALAR instruction (s_xor / s_andn2).  A v_writelane in inline asm that reads an SGPR the v_cmp right
+    // in front of it has just written gets the OLD value on gfx950 (the compiler's hazard recogniser pads its own
+    // instructions, not the inside of an asm statement): measured with edge 0's arg-min mask of degree-1 rows
+    // (profiles/microbench/rec_row_equivalence.hip).
+    u64 found;
+    asm volatile("s_mov_b64 %0, 0" : "=s"(found));
 #pragma unroll
     for (int k = 0; k < DEG; k++) {
-        const u64 ng = __ballot((par ^ (unsigned)(x[k] <= 0.0f)) != 0);
-        const u64 ag = __ballot(ix == k);
-        if (lane == k) {
-            mneg = ng;
-            marg = ag;
-        }
+        const u64 ng = __ballot(x[k] <= 0.0f) ^ par;
+        const u64 eq = __ballot(fabsf(x[k]) == m1);
+        const u64 ag = eq & ~found;
+        found |= eq;
+        asm("v_writelane_b32 %0, %1, %2" : "+v"(nlo) : "s"((unsigned)ng), "n"(k));
+        asm("v_writelane_b32 %0, %1, %2" : "+v"(nhi) : "s"((unsigned)(ng >> 32)), "n"(k));
+        asm("v_writelane_b32 %0, %1, %2" : "+v"(alo) : "s"((unsigned)ag), "n"(k));
+        asm("v_writelane_b32 %0, %1, %2" : "+v"(ahi) : "s"((unsigned)(ag >> 32)), "n"(k));
     }
-    if (lane < DEG) mask[lane] = make_ulonglong2(mneg, marg);
+    if (lane < DEG) mask[lane] = make_ulonglong2(((u64)nhi << 32) | nlo, ((u64)ahi << 32) | alo);
 }
 
 template <int CAP, bool FIRST, bool PAR = false>
@@ -695,12 +718,12 @@ __global__ __launch_bounds__(256) void k_check_minsum_rec(const int *__restrict_
         const int e0 = md[1];
         const int deg = md[2];
         const float *p = msg + ((size_t)tl * E + e0) * TW + lane;
-        float *rc = rec + ((size_t)tl * m + r) * 2 * TW;
+        float *rc = rec + ((size_t)tl * 2 * m + r) * TW, *rc2 = rc + (size_t)m * TW;  // two planes per tile: [m1 | m2][row][64]
         ulonglong2 *mk = mask + (size_t)tl * E + e0;
-        const unsigned sbit = (unsigned)(synd[(size_t)tl * m + r] >> lane) & 1u;
+        const u64 sw = synd[(size_t)tl * m + r];  // (uniform: a scalar load; the row's syndrome bits ARE a lane mask)
 #define MR(D)                                                                                                       \
     case D:                                                                                                         \
-        if constexpr (D <= CAP) check_minsum_row_rec<D, FIRST>(p, sbit, alpha, prior, col_idx + e0, rc, mk, lane);  \
+        if constexpr (D <= CAP) check_minsum_row_rec<D, FIRST>(p, sw, alpha, prior, col_idx + e0, rc, rc2, mk, lane);    \
         break;
 #define MR8(D) MR(D) MR(D + 1) MR(D + 2) MR(D + 3) MR(D + 4) MR(D + 5) MR(D + 6) MR(D + 7)
         switch (deg) {
@@ -1343,46 +1366,63 @@ __global__ __launch_bounds__(256) void k_var_first(const int *__restrict__ list,
 }
 
 // Variable pass of the min-sum RECORD form (see k_check_minsum_rec): the column's messages are rebuilt from the
-// records of its edges' rows.  Lane j fetches the j-th edge of the column and that edge's row (one round trip), then
-// the edge's two lane masks (a second one); edge k's triple reaches every lane through v_readlane, the record values
-// come as gathers with the row on the scalar side -- all of them issued before the first is used, the second
-// magnitude only for the lanes whose arg-min this edge is (one in `row degree` on average).
-//   csc_row: row of every position of the re-laid edge list (laid out like it)
-template <int MAXD>
-__device__ __forceinline__ float var_col_rec(float *tile_base, const float *__restrict__ rec_base, unsigned lane,
-                                             const int4 *__restrict__ rec4, const int *__restrict__ ce1, int rowv,
-                                             ulonglong2 mk, int d, float pr)
+// records of its edges' rows.  The wave's column record carries the first VAR_INLINE edge ids, a parallel table the
+// rows of those edges (`var_rows`, VAR_INLINE ints per record), both through scalar loads: the first-magnitude
+// gathers (row on the scalar side) issue as soon as the record is in.  Beside them lane j fetches the two lane masks
+// of the column's j-th edge (its id put into the lane with v_writelane); edge k's masks then reach every lane through
+// v_readlane, and the second magnitude is fetched only for the lanes whose arg-min this edge is (one in `row degree`
+// on average).  All gathers of the column are in flight before the first one is waited for.
+//   csc_row: row of every position of the re-laid edge list (laid out like it), for edges beyond VAR_INLINE
+template <int MAXD, bool SC1>
+__device__ __forceinline__ float var_col_rec(float *tile_base, const float *__restrict__ rec_base,
+                                             const float *__restrict__ rec2_base, unsigned lane,
+                                             const int4 *__restrict__ rec4, const int4 *__restrict__ row4,
+                                             const int *__restrict__ ce1, const int *__restrict__ cr1, ulonglong2 mk, int d, float pr)
 {
-    int eid[MAXD];
+    int eid[MAXD], rid[MAXD];
     {
         const int4 a = rec4[1], b = rec4[2], c = rec4[3], e = rec4[4];
         const int in16[16] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, c.x, c.y, c.z, c.w, e.x, e.y, e.z, e.w};
+        const int4 ra = row4[0], rb = row4[1], rc = row4[2], re = row4[3];
+        const int rw16[16] = {ra.x, ra.y, ra.z, ra.w, rb.x, rb.y, rb.z, rb.w, rc.x, rc.y, rc.z, rc.w, re.x, re.y, re.z, re.w};
 #pragma unroll
-        for (int k = 0; k < MAXD && k < VAR_INLINE; k++) eid[k] = in16[k];
+        for (int k = 0; k < MAXD && k < VAR_INLINE; k++) {
+            eid[k] = in16[k];
+            rid[k] = rw16[k];
+        }
 #pragma unroll
-        for (int k = VAR_INLINE; k < MAXD; k++) eid[k] = ce1[k];
+        for (int k = VAR_INLINE; k < MAXD; k++) {
+            eid[k] = ce1[k];  // (both lists are padded: reads past a column stay inside them)
+            rid[k] = cr1[k];
+        }
     }
     float mm[MAXD], pp[MAXD], m2[MAXD];
     const int nlo = (int)(unsigned)mk.x, nhi = (int)(unsigned)(mk.x >> 32), alo = (int)(unsigned)mk.y, ahi = (int)(unsigned)(mk.y >> 32);
-    // three sweeps, so that every gather of the column is in flight before the first one is waited for: the first
-    // magnitudes, the second ones (only the lanes whose arg-min the edge is), then select + sign
-#pragma unroll
-    for (int k = 0; k < MAXD; k++)
-        if (k < d) mm[k] = (rec_base + (size_t)__builtin_amdgcn_readlane(rowv, k) * (2 * TW))[lane];
+    // Three sweeps, so that every gather of the column is in flight before the first one is waited for: the first
+    // magnitudes, the second ones (only the lanes whose arg-min the edge is), then select + sign.  An edge's masks
+    // are wave-uniform 64-bit words: they go straight into the select / execute-mask operands
+    // (__builtin_amdgcn_inverse_ballot_w64), no per-lane shift-and-test -- this pass is bound by VALU issue (a wave64
+    // instruction occupies the SIMD for 4 cycles; at ~30 instructions per edge the pass took 60 us with or without
+    // its stores), so the instruction count per edge is what matters.
+    u64 ag[MAXD];
 #pragma unroll
     for (int k = 0; k < MAXD; k++)
         if (k < d) {
-            const u64 ag = ((u64)(unsigned)__builtin_amdgcn_readlane(ahi, k) << 32) | (unsigned)__builtin_amdgcn_readlane(alo, k);
+            mm[k] = (rec_base + (size_t)rfl(rid[k]) * TW)[lane];
+        }
+#pragma unroll
+    for (int k = 0; k < MAXD; k++)
+        if (k < d) {
+            ag[k] = ((u64)(unsigned)__builtin_amdgcn_readlane(ahi, k) << 32) | (unsigned)__builtin_amdgcn_readlane(alo, k);
             m2[k] = 0.0f;
-            if ((ag >> lane) & 1) m2[k] = (rec_base + (size_t)__builtin_amdgcn_readlane(rowv, k) * (2 * TW) + TW)[lane];
+            if (__builtin_amdgcn_inverse_ballot_w64(ag[k])) m2[k] = (rec2_base + (size_t)rfl(rid[k]) * TW)[lane];
         }
 #pragma unroll
     for (int k = 0; k < MAXD; k++)
         if (k < d) {
             const u64 ng = ((u64)(unsigned)__builtin_amdgcn_readlane(nhi, k) << 32) | (unsigned)__builtin_amdgcn_readlane(nlo, k);
-            const u64 ag = ((u64)(unsigned)__builtin_amdgcn_readlane(ahi, k) << 32) | (unsigned)__builtin_amdgcn_readlane(alo, k);
-            const float a = ((ag >> lane) & 1) ? m2[k] : mm[k];
-            mm[k] = __uint_as_float(__float_as_uint(a) ^ (((unsigned)(ng >> lane) & 1u) << 31));
+            const float a = __builtin_amdgcn_inverse_ballot_w64(ag[k]) ? m2[k] : mm[k];
+            mm[k] = __builtin_amdgcn_inverse_ballot_w64(ng) ? -a : a;
         }
     float temp = pr;
 #pragma unroll
@@ -1395,63 +1435,72 @@ __device__ __forceinline__ float var_col_rec(float *tile_base, const float *__re
 #pragma unroll
     for (int k = MAXD - 1; k >= 0; k--)
         if (k < d) {
-            (tile_base + (size_t)rfl(eid[k]) * TW)[lane] = pp[k] + suf;
+            float *q = tile_base + (size_t)rfl(eid[k]) * TW + lane;
+            if constexpr (SC1)
+                __hip_atomic_store(q, pp[k] + suf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // sc1: the line does not stay in this XCD's L2
+            else
+                *q = pp[k] + suf;
             suf += mm[k];
         }
     return temp;
 }
 
 // grid (bk.blk[nb], G), block 256 = 4 column records (k_var's launch shape and records).
-template <int CAP>
-__global__ __launch_bounds__(256) void k_var_rec(const int *__restrict__ list, const int *__restrict__ csc_edge,
-                                                 const int *__restrict__ csc_row, const float *__restrict__ prior, float *msg,
-                                                 const float *__restrict__ rec, const ulonglong2 *__restrict__ mask,
-                                                 float *__restrict__ post, u64 *__restrict__ hard, const u64 *__restrict__ done,
-                                                 int skip_done, int n, int m, long E, int write_out)
+// SC1: the message stores leave this XCD's L2 (they are read next by a check pass on whichever XCD), which keeps the
+// L2 for the records: 76.2 -> 74.3 ms per step on the HQC-128 bench (profiles/r03/ab_rec_l2.log).
+template <int CAP, bool SC1 = false>
+__global__ __launch_bounds__(256) void k_var_rec(const int *__restrict__ list, const int *__restrict__ var_rows,
+                                                 const int *__restrict__ csc_edge, const int *__restrict__ csc_row,
+                                                 const float *__restrict__ prior, float *msg, const float *__restrict__ rec,
+                                                 const ulonglong2 *__restrict__ mask, float *__restrict__ post,
+                                                 u64 *__restrict__ hard, const u64 *__restrict__ done, int skip_done, int n, int m,
+                                                 long E, int write_out)
 {
     const unsigned lane = threadIdx.x & 63u;
     const int tl = blockIdx.y;
-    const int *rc = list + (size_t)rfl((int)blockIdx.x * 4 + (int)(threadIdx.x >> 6)) * VAR_REC;
+    const int ri = rfl((int)blockIdx.x * 4 + (int)(threadIdx.x >> 6));
+    const int *rc = list + (size_t)ri * VAR_REC;
     const u64 dn = done[tl];
     if (skip_done && dn == ~0ull) return;
     const int v = rc[0];
     if (v < 0) return;
     const int cb = rc[1];
     const int d = rc[2];
-    int ej = 0, rowv = 0;
-    if ((int)lane < d) {
-        ej = csc_edge[(size_t)cb + lane];
-        rowv = csc_row[(size_t)cb + lane];
-    }
+    // lane j's edge id: the record's inline ids go into the lanes with v_writelane (no memory round trip), the rest
+    // of a long column comes from the list
+    int ej = 0;
+#pragma unroll
+    for (int k = 0; k < VAR_INLINE; k++) asm("v_writelane_b32 %0, %1, %2" : "+v"(ej) : "s"(rc[4 + k]), "n"(k));
+    if (d > VAR_INLINE && (int)lane >= VAR_INLINE && (int)lane < d) ej = csc_edge[(size_t)cb + lane];
     ulonglong2 mk = make_ulonglong2(0, 0);
     if ((int)lane < d) mk = mask[(size_t)tl * E + ej];
     {
-        // ONE unconditional use of the loaded registers: the wait for the loads above then sits here.  Without it the
+        // ONE unconditional use of the loaded registers: the wait for the load above then sits here.  Without it the
         // first use is inside a block predicated on `k < d`, the skipped path has not waited, and the compiler guards
         // every later predicated block with its own `s_waitcnt vmcnt(0)` -- in front of each gather, i.e. the gathers
-        // of a column run one after the other (measured: 80 us per launch against 64 for the message form).
+        // of a column run one after the other (measured: 80 us per launch against 64).  It sits BEHIND the
+        // first-magnitude gathers in program order only if the compiler keeps it there: the asm is not volatile.
         unsigned a = (unsigned)mk.x, b = (unsigned)(mk.x >> 32), c = (unsigned)mk.y, e = (unsigned)(mk.y >> 32);
-        asm volatile("v_mov_b32 %0, %0\n\tv_mov_b32 %1, %1\n\tv_mov_b32 %2, %2\n\tv_mov_b32 %3, %3\n\tv_mov_b32 %4, %4"
-                     : "+v"(rowv), "+v"(a), "+v"(b), "+v"(c), "+v"(e));
+        asm("v_mov_b32 %0, %0\n\tv_mov_b32 %1, %1\n\tv_mov_b32 %2, %2\n\tv_mov_b32 %3, %3" : "+v"(a), "+v"(b), "+v"(c), "+v"(e));
         mk = make_ulonglong2(((u64)b << 32) | a, ((u64)e << 32) | c);
     }
     float *tb = msg + (size_t)tl * E * TW;
-    const float *rb = rec + (size_t)tl * m * 2 * TW;
-    const int *ce = csc_edge + cb;
-    const int4 *r4 = (const int4 *)rc;
+    const float *rb = rec + (size_t)tl * 2 * m * TW, *rb2 = rb + (size_t)m * TW;
+    const int *ce = csc_edge + cb, *cr = csc_row + cb;
+    const int4 *r4 = (const int4 *)rc, *w4 = (const int4 *)(var_rows + (size_t)ri * VAR_INLINE);
     const float pr = prior[v];
     float L = pr;
     switch (rc[3]) {
-        case 1: L = var_col_rec<1>(tb, rb, lane, r4, ce, rowv, mk, d, pr); break;
-        case 2: L = var_col_rec<2>(tb, rb, lane, r4, ce, rowv, mk, d, pr); break;
-        case 4: L = var_col_rec<4>(tb, rb, lane, r4, ce, rowv, mk, d, pr); break;
-        case 8: L = var_col_rec<8>(tb, rb, lane, r4, ce, rowv, mk, d, pr); break;
-        case 16: L = var_col_rec<16>(tb, rb, lane, r4, ce, rowv, mk, d, pr); break;
+        case 1: L = var_col_rec<1, SC1>(tb, rb, rb2, lane, r4, w4, ce, cr, mk, d, pr); break;
+        case 2: L = var_col_rec<2, SC1>(tb, rb, rb2, lane, r4, w4, ce, cr, mk, d, pr); break;
+        case 4: L = var_col_rec<4, SC1>(tb, rb, rb2, lane, r4, w4, ce, cr, mk, d, pr); break;
+        case 8: L = var_col_rec<8, SC1>(tb, rb, rb2, lane, r4, w4, ce, cr, mk, d, pr); break;
+        case 16: L = var_col_rec<16, SC1>(tb, rb, rb2, lane, r4, w4, ce, cr, mk, d, pr); break;
         case 32:
-            if constexpr (CAP >= 32) L = var_col_rec<32>(tb, rb, lane, r4, ce, rowv, mk, d, pr);
+            if constexpr (CAP >= 32) L = var_col_rec<32, SC1>(tb, rb, rb2, lane, r4, w4, ce, cr, mk, d, pr);
             break;
         case 64:
-            if constexpr (CAP >= 64) L = var_col_rec<64>(tb, rb, lane, r4, ce, rowv, mk, d, pr);
+            if constexpr (CAP >= 64) L = var_col_rec<64, SC1>(tb, rb, rb2, lane, r4, w4, ce, cr, mk, d, pr);
             break;
         default: break;  // (no any-degree columns when this kernel is launched)
     }
