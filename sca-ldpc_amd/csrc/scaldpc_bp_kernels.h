@@ -1368,80 +1368,82 @@ __global__ __launch_bounds__(256) void k_var_first(const int *__restrict__ list,
 // Variable pass of the min-sum RECORD form (see k_check_minsum_rec): the column's messages are rebuilt from the
 // records of its edges' rows.  The wave's column record carries the first VAR_INLINE edge ids, a parallel table the
 // rows of those edges (`var_rows`, VAR_INLINE ints per record), both through scalar loads: the first-magnitude
-// gathers (row on the scalar side) issue as soon as the record is in.  Beside them lane j fetches the two lane masks
-// of the column's j-th edge (its id put into the lane with v_writelane); edge k's masks then reach every lane through
-// v_readlane, and the second magnitude is fetched only for the lanes whose arg-min this edge is (one in `row degree`
-// on average).  All gathers of the column are in flight before the first one is waited for.
+// gathers (row on the scalar side) issue as soon as the masks are in.  Lane j fetches the two lane masks of the
+// column's j-th edge (its id put into the lane with v_writelane: no memory round trip); edge k's masks then reach
+// every lane through v_readlane as wave-uniform 64-bit words that go straight into the select / execute-mask
+// operands (__builtin_amdgcn_inverse_ballot_w64), and the second magnitude is fetched only for the lanes whose
+// arg-min this edge is (one in `row degree` on average).  All gathers of the column are in flight before the first one
+// is waited for.
+// Like the record-form check pass this kernel is bound by VALU issue (SQ counters: profiles/r03/sq_counters_*record*;
+// without its stores it took 58 us instead of 60, without the first-magnitude gathers 52), so it is straight-line code
+// for the column's EXACT degree, dispatched wave-uniformly: the bucketed form (unrolled to the bucket's bound,
+// predicated on `k < d`) spent more instructions on the predicates than on the column.
 //   csc_row: row of every position of the re-laid edge list (laid out like it), for edges beyond VAR_INLINE
-template <int MAXD, bool SC1>
+template <int D, bool SC1>
 __device__ __forceinline__ float var_col_rec(float *tile_base, const float *__restrict__ rec_base,
-                                             const float *__restrict__ rec2_base, unsigned lane,
-                                             const int4 *__restrict__ rec4, const int4 *__restrict__ row4,
-                                             const int *__restrict__ ce1, const int *__restrict__ cr1, ulonglong2 mk, int d, float pr)
+                                             const float *__restrict__ rec2_base, const ulonglong2 *__restrict__ mask_tile,
+                                             unsigned lane, const int *__restrict__ rc, const int4 *__restrict__ row4,
+                                             const int *__restrict__ ce1, const int *__restrict__ cr1, float pr)
 {
-    int eid[MAXD], rid[MAXD];
+    int eid[D], rid[D];
     {
+        const int4 *rec4 = (const int4 *)rc;
         const int4 a = rec4[1], b = rec4[2], c = rec4[3], e = rec4[4];
         const int in16[16] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, c.x, c.y, c.z, c.w, e.x, e.y, e.z, e.w};
-        const int4 ra = row4[0], rb = row4[1], rc = row4[2], re = row4[3];
-        const int rw16[16] = {ra.x, ra.y, ra.z, ra.w, rb.x, rb.y, rb.z, rb.w, rc.x, rc.y, rc.z, rc.w, re.x, re.y, re.z, re.w};
+        const int4 ra = row4[0], rb = row4[1], rc4 = row4[2], re = row4[3];
+        const int rw16[16] = {ra.x, ra.y, ra.z, ra.w, rb.x, rb.y, rb.z, rb.w, rc4.x, rc4.y, rc4.z, rc4.w, re.x, re.y, re.z, re.w};
 #pragma unroll
-        for (int k = 0; k < MAXD && k < VAR_INLINE; k++) {
+        for (int k = 0; k < D && k < VAR_INLINE; k++) {
             eid[k] = in16[k];
             rid[k] = rw16[k];
         }
 #pragma unroll
-        for (int k = VAR_INLINE; k < MAXD; k++) {
-            eid[k] = ce1[k];  // (both lists are padded: reads past a column stay inside them)
+        for (int k = VAR_INLINE; k < D; k++) {
+            eid[k] = ce1[k];
             rid[k] = cr1[k];
         }
     }
-    float mm[MAXD], pp[MAXD], m2[MAXD];
+    // lane j's edge id, then its two masks
+    int ej = 0;
+#pragma unroll
+    for (int k = 0; k < D && k < VAR_INLINE; k++) asm("v_writelane_b32 %0, %1, %2" : "+v"(ej) : "s"(eid[k]), "n"(k));
+    if constexpr (D > VAR_INLINE)
+        if ((int)lane >= VAR_INLINE && (int)lane < D) ej = ce1[lane];
+    ulonglong2 mk = make_ulonglong2(0, 0);
+    if ((int)lane < D) mk = mask_tile[ej];
     const int nlo = (int)(unsigned)mk.x, nhi = (int)(unsigned)(mk.x >> 32), alo = (int)(unsigned)mk.y, ahi = (int)(unsigned)(mk.y >> 32);
-    // Three sweeps, so that every gather of the column is in flight before the first one is waited for: the first
-    // magnitudes, the second ones (only the lanes whose arg-min the edge is), then select + sign.  An edge's masks
-    // are wave-uniform 64-bit words: they go straight into the select / execute-mask operands
-    // (__builtin_amdgcn_inverse_ballot_w64), no per-lane shift-and-test -- this pass is bound by VALU issue (a wave64
-    // instruction occupies the SIMD for 4 cycles; at ~30 instructions per edge the pass took 60 us with or without
-    // its stores), so the instruction count per edge is what matters.
-    u64 ag[MAXD];
+    float mm[D], pp[D], m2[D];
+    u64 ag[D];
 #pragma unroll
-    for (int k = 0; k < MAXD; k++)
-        if (k < d) {
-            mm[k] = (rec_base + (size_t)rfl(rid[k]) * TW)[lane];
-        }
+    for (int k = 0; k < D; k++) mm[k] = (rec_base + (size_t)rfl(rid[k]) * TW)[lane];
 #pragma unroll
-    for (int k = 0; k < MAXD; k++)
-        if (k < d) {
-            ag[k] = ((u64)(unsigned)__builtin_amdgcn_readlane(ahi, k) << 32) | (unsigned)__builtin_amdgcn_readlane(alo, k);
-            m2[k] = 0.0f;
-            if (__builtin_amdgcn_inverse_ballot_w64(ag[k])) m2[k] = (rec2_base + (size_t)rfl(rid[k]) * TW)[lane];
-        }
+    for (int k = 0; k < D; k++) {
+        ag[k] = ((u64)(unsigned)__builtin_amdgcn_readlane(ahi, k) << 32) | (unsigned)__builtin_amdgcn_readlane(alo, k);
+        asm("" : "=v"(m2[k]));  // (any value: read only where the load below has written it)
+        if (__builtin_amdgcn_inverse_ballot_w64(ag[k])) m2[k] = (rec2_base + (size_t)rfl(rid[k]) * TW)[lane];
+    }
 #pragma unroll
-    for (int k = 0; k < MAXD; k++)
-        if (k < d) {
-            const u64 ng = ((u64)(unsigned)__builtin_amdgcn_readlane(nhi, k) << 32) | (unsigned)__builtin_amdgcn_readlane(nlo, k);
-            const float a = __builtin_amdgcn_inverse_ballot_w64(ag[k]) ? m2[k] : mm[k];
-            mm[k] = __builtin_amdgcn_inverse_ballot_w64(ng) ? -a : a;
-        }
+    for (int k = 0; k < D; k++) {
+        const u64 ng = ((u64)(unsigned)__builtin_amdgcn_readlane(nhi, k) << 32) | (unsigned)__builtin_amdgcn_readlane(nlo, k);
+        const float a = __builtin_amdgcn_inverse_ballot_w64(ag[k]) ? m2[k] : mm[k];
+        mm[k] = __builtin_amdgcn_inverse_ballot_w64(ng) ? -a : a;
+    }
     float temp = pr;
 #pragma unroll
-    for (int k = 0; k < MAXD; k++)
-        if (k < d) {
-            pp[k] = temp;
-            temp += mm[k];
-        }
+    for (int k = 0; k < D; k++) {
+        pp[k] = temp;
+        temp += mm[k];
+    }
     float suf = 0.0f;
 #pragma unroll
-    for (int k = MAXD - 1; k >= 0; k--)
-        if (k < d) {
-            float *q = tile_base + (size_t)rfl(eid[k]) * TW + lane;
-            if constexpr (SC1)
-                __hip_atomic_store(q, pp[k] + suf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // sc1: the line does not stay in this XCD's L2
-            else
-                *q = pp[k] + suf;
-            suf += mm[k];
-        }
+    for (int k = D - 1; k >= 0; k--) {
+        float *q = tile_base + (size_t)rfl(eid[k]) * TW + lane;
+        if constexpr (SC1)
+            __hip_atomic_store(q, pp[k] + suf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // sc1: the line does not stay in this XCD's L2
+        else
+            *q = pp[k] + suf;
+        suf += mm[k];
+    }
     return temp;
 }
 
@@ -1466,44 +1468,26 @@ __global__ __launch_bounds__(256) void k_var_rec(const int *__restrict__ list, c
     if (v < 0) return;
     const int cb = rc[1];
     const int d = rc[2];
-    // lane j's edge id: the record's inline ids go into the lanes with v_writelane (no memory round trip), the rest
-    // of a long column comes from the list
-    int ej = 0;
-#pragma unroll
-    for (int k = 0; k < VAR_INLINE; k++) asm("v_writelane_b32 %0, %1, %2" : "+v"(ej) : "s"(rc[4 + k]), "n"(k));
-    if (d > VAR_INLINE && (int)lane >= VAR_INLINE && (int)lane < d) ej = csc_edge[(size_t)cb + lane];
-    ulonglong2 mk = make_ulonglong2(0, 0);
-    if ((int)lane < d) mk = mask[(size_t)tl * E + ej];
-    {
-        // ONE unconditional use of the loaded registers: the wait for the load above then sits here.  Without it the
-        // first use is inside a block predicated on `k < d`, the skipped path has not waited, and the compiler guards
-        // every later predicated block with its own `s_waitcnt vmcnt(0)` -- in front of each gather, i.e. the gathers
-        // of a column run one after the other (measured: 80 us per launch against 64).  It sits BEHIND the
-        // first-magnitude gathers in program order only if the compiler keeps it there: the asm is not volatile.
-        unsigned a = (unsigned)mk.x, b = (unsigned)(mk.x >> 32), c = (unsigned)mk.y, e = (unsigned)(mk.y >> 32);
-        asm("v_mov_b32 %0, %0\n\tv_mov_b32 %1, %1\n\tv_mov_b32 %2, %2\n\tv_mov_b32 %3, %3" : "+v"(a), "+v"(b), "+v"(c), "+v"(e));
-        mk = make_ulonglong2(((u64)b << 32) | a, ((u64)e << 32) | c);
-    }
     float *tb = msg + (size_t)tl * E * TW;
     const float *rb = rec + (size_t)tl * 2 * m * TW, *rb2 = rb + (size_t)m * TW;
+    const ulonglong2 *mt = mask + (size_t)tl * E;
     const int *ce = csc_edge + cb, *cr = csc_row + cb;
-    const int4 *r4 = (const int4 *)rc, *w4 = (const int4 *)(var_rows + (size_t)ri * VAR_INLINE);
+    const int4 *w4 = (const int4 *)(var_rows + (size_t)ri * VAR_INLINE);
     const float pr = prior[v];
     float L = pr;
-    switch (rc[3]) {
-        case 1: L = var_col_rec<1, SC1>(tb, rb, rb2, lane, r4, w4, ce, cr, mk, d, pr); break;
-        case 2: L = var_col_rec<2, SC1>(tb, rb, rb2, lane, r4, w4, ce, cr, mk, d, pr); break;
-        case 4: L = var_col_rec<4, SC1>(tb, rb, rb2, lane, r4, w4, ce, cr, mk, d, pr); break;
-        case 8: L = var_col_rec<8, SC1>(tb, rb, rb2, lane, r4, w4, ce, cr, mk, d, pr); break;
-        case 16: L = var_col_rec<16, SC1>(tb, rb, rb2, lane, r4, w4, ce, cr, mk, d, pr); break;
-        case 32:
-            if constexpr (CAP >= 32) L = var_col_rec<32, SC1>(tb, rb, rb2, lane, r4, w4, ce, cr, mk, d, pr);
-            break;
-        case 64:
-            if constexpr (CAP >= 64) L = var_col_rec<64, SC1>(tb, rb, rb2, lane, r4, w4, ce, cr, mk, d, pr);
-            break;
-        default: break;  // (no any-degree columns when this kernel is launched)
+#define VR(D)                                                                                   \
+    case D:                                                                                     \
+        if constexpr (D <= CAP) L = var_col_rec<D, SC1>(tb, rb, rb2, mt, lane, rc, w4, ce, cr, pr); \
+        break;
+#define VR8(D) VR(D) VR(D + 1) VR(D + 2) VR(D + 3) VR(D + 4) VR(D + 5) VR(D + 6) VR(D + 7)
+    switch (d) {
+        VR(1) VR(2) VR(3) VR(4) VR(5) VR(6) VR(7)
+        VR8(8) VR8(16) VR8(24) VR8(32) VR8(40) VR8(48) VR8(56)
+        VR(64)
+        default: break;  // (degree 0: the posterior is the prior; degrees beyond 64 never reach this kernel)
     }
+#undef VR8
+#undef VR
     if (write_out) {
         const u64 hb = __ballot(L <= 0.0f);
         const size_t hi = (size_t)tl * n + v;

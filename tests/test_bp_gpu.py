@@ -415,6 +415,95 @@ def test_convergence_test_riding_on_the_check_pass_is_invisible(oracle, method):
         assert len(np.unique(ref["iters"])) > 3  # a spread of iteration counts, so that latching at the right one matters
 
 
+def test_minsum_record_form_is_invisible(oracle):
+    """Min-sum on the tile kernels runs in a RECORD form by default (`minsum_rec`): the check pass writes, per row and
+    codeword, the two magnitudes a min-sum check sends and, per edge, two lane masks (sign, arg-min) instead of a message
+    per edge, and the variable pass rebuilds every message from them.  Results are those of the message form, bit for
+    bit -- decisions, posteriors, iteration counts, flags -- and those of the oracle: HQC-shaped and irregular graphs
+    (rows of degree 0, 1, 2 ... and columns beyond the records' inline edges), +-inf priors (NaN messages: inf - inf),
+    the alpha = 1 - 2^-it schedule, early exit with the convergence test riding on the record check pass and without,
+    the first iteration with and without its check pass, one and two stream lanes, compaction, plain and sc1 stores,
+    rows appended to a live decoder.  A graph with a row wider than 64 falls back to the message form by itself."""
+    rng = np.random.RandomState(77)
+    cases = []
+    for eps, alpha in ((0.03, 1.0), (0.0, 0.0), (0.03, 0.625)):
+        H, Hin, probs, msg, y = hqc_instance(1201, 9, 420, 6, eps, 333, seed=62, flip=eps > 0)
+        cases.append((H, probs, msg, "received_vector", alpha))
+    Hd = (rng.rand(150, 380) < 0.03).astype(np.int8)
+    Hd[5] = 0  # an empty row
+    Hd[6] = 0
+    Hd[6, 17] = 1  # rows of degree 1 and 2: the arg-min edge takes the FLT_MAX second minimum
+    Hd[7] = 0
+    Hd[7, [3, 200]] = 1
+    Hd[:, 11] = 0
+    Hd[:40, 11] = 1  # a column of degree 40: beyond the inline edges of its record
+    G2 = S.TannerGraph.from_dense(Hd)
+    p2 = rng.uniform(0.01, 0.1, size=380)
+    p2[rng.rand(380) < 0.1] = 0.0  # certain positions: +-inf priors, inf - inf = NaN messages
+    s2 = G2.syndrome((rng.rand(300, 380) < np.maximum(p2, 0.02)[None, :]).astype(np.uint8))
+    cases.append((G2, p2, s2, "syndrome", 0.75))
+    for graph, pr, x, kind, alpha in cases:
+        outs = {}
+        for form in ((1, 1), (1, 0), (0, 0)):  # (minsum_rec, rec_sc1)
+            res = []
+            for lanes, group, compact, ff, ft in ((2, 3, -1, 1, 1), (1, 2, 0, 0, 1), (2, 0, 2, 1, 0)):
+                with np.errstate(divide="ignore"):
+                    dec = bp.bp_decoder(graph, max_iter=30, bp_method="min_sum", channel_probs=pr, ms_scaling_factor=alpha)
+                dec.configure(path="stream", minsum_rec=form[0], rec_sc1=form[1], split=lanes, compact_after=compact, first_fused=ff,
+                              fuse_test=ft)
+                dec.set_tile_group(group)
+                res.append(dec.decode_batch(x, early_exit=True, want_llr=True, input_vector_type=kind))
+                res.append(dec.decode_batch(x[:70], early_exit=False, want_llr=True, input_vector_type=kind))
+                assert dec.time_kernels(2)["record_form"] == bool(form[0])  # the form that ran is the one asked for
+                dec.close()
+            outs[form] = res
+        for form in ((1, 1), (1, 0)):
+            for a, b in zip(outs[form], outs[(0, 0)]):
+                for k in ("bits", "llr", "iters", "converged"):
+                    assert np.array_equal(a[k], b[k], equal_nan=(k == "llr")), (alpha, form, k)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            ref = oracle.bp_decode_batch(graph, pr, x, 1 if kind == "received_vector" else 0, 30, "min_sum", alpha=alpha, dtype="f32",
+                                         threads=8)
+        compare(outs[(1, 1)][0], ref, "min_sum")
+    # rows appended to a live decoder: records and masks are sized by the graph
+    H, Hin, probs, msg, y = hqc_instance(901, 9, 300, 6, 0.03, 150, seed=63)
+    N = 901
+
+    def graph(r):
+        rp = Hin.row_ptr[: r + 1]
+        cols = np.concatenate([Hin.col_idx[: rp[-1]].reshape(r, -1), N + np.arange(r, dtype=np.int32)[:, None]], axis=1)
+        return S.TannerGraph.from_csr(r, N + r, np.arange(r + 1, dtype=np.int64) * cols.shape[1], cols.reshape(-1))
+
+    outs = {}
+    for rec in (1, 0):
+        dec = bp.bp_decoder(graph(200), max_iter=20, bp_method="min_sum", channel_probs=probs[: N + 200])
+        dec.configure(path="stream", minsum_rec=rec)
+        a = dec.decode_batch(msg[:, : N + 200], early_exit=True, want_llr=True)
+        g = graph(300)
+        e0 = g.row_ptr[200]
+        dec.append_rows(g.row_ptr[200:] - e0, g.col_idx[e0:], N + 300, probs[N + 200 :])
+        b = dec.decode_batch(msg, early_exit=True, want_llr=True)
+        dec.close()
+        outs[rec] = (a, b)
+    for a, b in zip(outs[1], outs[0]):
+        for k in ("bits", "llr", "iters", "converged"):
+            assert np.array_equal(a[k], b[k], equal_nan=(k == "llr")), k
+    ref = oracle.bp_decode_batch(H, probs, msg, 1, 20, "min_sum", dtype="f32", threads=8)
+    compare(outs[1][1], ref, "min_sum")
+    # a row wider than a wave: the message form, whatever the knob says
+    Hw = (rng.rand(30, 200) < 0.1).astype(np.int8)
+    Hw[0, :70] = 1
+    Gw = S.TannerGraph.from_dense(Hw)
+    pw = rng.uniform(0.01, 0.1, size=200)
+    sw = Gw.syndrome((rng.rand(100, 200) < pw[None, :]).astype(np.uint8))
+    dec = bp.bp_decoder(Gw, max_iter=10, bp_method="min_sum", channel_probs=pw)
+    dec.configure(path="stream", minsum_rec=1)
+    got = dec.decode_batch(sw, early_exit=True, want_llr=True, input_vector_type="syndrome")
+    assert dec.time_kernels(2)["record_form"] is False
+    dec.close()
+    compare(got, oracle.bp_decode_batch(Gw, pw, sw, 0, 10, "min_sum", dtype="f32", threads=4), "min_sum")
+
+
 @pytest.mark.parametrize("method", ["min_sum", "product_sum"])
 def test_full_size_invariances(method, decode_path):
     """Size-independent properties at BASELINE config 2's full size (HQC-128 graph, batch 4096, no oracle needed):
