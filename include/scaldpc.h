@@ -206,6 +206,8 @@ int scaldpc_bp_last_stats(scaldpc_bp *h, int64_t *out);
  *                   row and codeword, the two magnitudes a min-sum check sends (8 B) and, per edge and tile, two lane
  *                   masks (sign, arg-min: 0.25 B per codeword) instead of 4 B per edge and codeword; the variable pass
  *                   rebuilds every message from them, bit for bit.  0 = messages both ways.  (SCALDPC_MINSUM_REC)
+ *   "rec_sc1"       1 (default) = the record form's variable pass stores its messages with sc1 (the line leaves the
+ *                   XCD's L2, which keeps it for the row records); 0 = plain stores (A/B).  (SCALDPC_REC_SC1)
  *   "first_fused"   1 (default) = iteration 1 of the tile kernels runs without its check pass: the first variable
  *                   pass takes the first check-to-variable messages from a per-edge table (the message of a
  *                   zero-syndrome codeword) and the row's syndrome bit; 0 = check pass + plain variable pass

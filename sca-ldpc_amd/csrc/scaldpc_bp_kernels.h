@@ -1379,6 +1379,17 @@ __global__ __launch_bounds__(256) void k_var_first(const int *__restrict__ list,
 // for the column's EXACT degree, dispatched wave-uniformly: the bucketed form (unrolled to the bucket's bound,
 // predicated on `k < d`) spent more instructions on the predicates than on the column.
 //   csc_row: row of every position of the re-laid edge list (laid out like it), for edges beyond VAR_INLINE
+// A wave-uniform pointer pinned to an SGPR pair: the access `sbase(p)[lane]` then takes the scalar-base form
+// (global_load/store v, v_lane_offset, s[base]) instead of a 64-bit VGPR address the compiler re-derives per edge with
+// a v_lshl_add_u64 -- one VALU instruction per access in a pass that is bound by VALU issue.
+typedef __attribute__((address_space(1))) float gfloat;  // (a pointer that went through an asm is no longer known to be global)
+__device__ __forceinline__ gfloat *sbase(const float *p)
+{
+    gfloat *g = (gfloat *)p;
+    asm("" : "+s"(g));
+    return g;
+}
+
 template <int D, bool SC1>
 __device__ __forceinline__ float var_col_rec(float *tile_base, const float *__restrict__ rec_base,
                                              const float *__restrict__ rec2_base, const ulonglong2 *__restrict__ mask_tile,
@@ -1415,12 +1426,12 @@ __device__ __forceinline__ float var_col_rec(float *tile_base, const float *__re
     float mm[D], pp[D], m2[D];
     u64 ag[D];
 #pragma unroll
-    for (int k = 0; k < D; k++) mm[k] = (rec_base + (size_t)rfl(rid[k]) * TW)[lane];
+    for (int k = 0; k < D; k++) mm[k] = sbase(rec_base + (size_t)rfl(rid[k]) * TW)[lane];
 #pragma unroll
     for (int k = 0; k < D; k++) {
         ag[k] = ((u64)(unsigned)__builtin_amdgcn_readlane(ahi, k) << 32) | (unsigned)__builtin_amdgcn_readlane(alo, k);
         asm("" : "=v"(m2[k]));  // (any value: read only where the load below has written it)
-        if (__builtin_amdgcn_inverse_ballot_w64(ag[k])) m2[k] = (rec2_base + (size_t)rfl(rid[k]) * TW)[lane];
+        if (__builtin_amdgcn_inverse_ballot_w64(ag[k])) m2[k] = sbase(rec2_base + (size_t)rfl(rid[k]) * TW)[lane];
     }
 #pragma unroll
     for (int k = 0; k < D; k++) {
@@ -1437,7 +1448,7 @@ __device__ __forceinline__ float var_col_rec(float *tile_base, const float *__re
     float suf = 0.0f;
 #pragma unroll
     for (int k = D - 1; k >= 0; k--) {
-        float *q = tile_base + (size_t)rfl(eid[k]) * TW + lane;
+        gfloat *q = sbase(tile_base + (size_t)rfl(eid[k]) * TW) + lane;
         if constexpr (SC1)
             __hip_atomic_store(q, pp[k] + suf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // sc1: the line does not stay in this XCD's L2
         else
