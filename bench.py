@@ -331,6 +331,14 @@ def main():
                 "row records (8m, re-read from L2 for every edge) read (variable): about 8.7E through the fabric")
         if live_traffic:
             out["roofline"]["traffic_all_kernels"] = live_traffic["kernels"]
+            tc, tv = live_traffic["kernels"].get(cpmc), live_traffic["kernels"].get(vname)
+            if tc and tv and live_traffic.get("codewords_per_launch") == swept:
+                # what the fabric really carried over a launch pair (PMC bytes of both kernels, every lane), beside the
+                # algorithmic figure `achieved` is defined on
+                moved = lanes * (tc["traffic_bytes"] + tv["traffic_bytes"]) / ((ms_check + ms_var_pass) * 1e-3) / 1e9
+                out["roofline"]["moved"] = {"GBps": moved, "frac_of_peak": moved / HBM_PEAK_GBS,
+                                            "bytes_per_pair_and_lane": tc["traffic_bytes"] + tv["traffic_bytes"],
+                                            "what": "FETCH_SIZE + WRITE_SIZE of the check and the variable launch, all lanes, over the pair's time"}
         if iso:
             ic = iso["ms_check"] / max(1, iso["launches_check"])
             iv = iso["ms_var"] / max(1, iso["launches_var"])
