@@ -14,7 +14,10 @@ Also reported on the same JSON line:
                 update, on every HQC workload; the check-node kernel is a close second), algorithmic
                 bytes per launch (8 B per edge per codeword of the cache-resident tile group it
                 sweeps) / HIP-event launch duration vs the 8 TB/s HBM peak; `hbm_frac` = the same
-                kernels streaming from HBM (tile group far beyond the Infinity Cache) / that peak
+                kernels streaming from HBM (tile group far beyond the Infinity Cache) / that peak.
+                Min-sum runs in a RECORD form by default (k_check_minsum_rec / k_var_rec) that
+                moves about half the bytes: `frac` keeps the survey's algorithmic figure (16 B per edge-iteration, as
+                SURVEY 8d prescribes) and can exceed 1; `roofline.moved` = the PMC bytes of the launch pair / its time
   cpu_baseline  the CPU oracle's f32 restatement (oracle/, a "port": the reference's own
                 decoder binaries cannot run here) on a bounded sample, host cores stated
 """

@@ -596,8 +596,8 @@ int ensure_el_tables(scaldpc_bp *h)
 bool rec_form(const scaldpc_bp *h, int method)
 {
     return method == SCALDPC_BP_MIN_SUM && h->kn.minsum_rec && h->kn.minsum_loop == 0 && h->kn.var_form == 1 && h->E > 0 &&
-           h->max_row_deg <= 64 && h->max_col_deg <= 64 && !h->hg_var.has_generic;
-}
+           h->max_row_deg <= 64 && h->max_col_deg <= 32 && !h->hg_var.has_generic;  // (columns of 33-64 edges: message form; the
+}                                                                                   //  exact-degree variable pass is compiled up to 32)
 
 // message array of the tile path, G tiles (and the records of the min-sum record form)
 int ensure_msg(scaldpc_bp *h, int G, int method)
@@ -834,9 +834,9 @@ int launch_var(scaldpc_bp *h, int G, float *post_g, u64 *hard_g, const u64 *done
                        h->d_prior, msg0, h->d_rec + (size_t)tile0 * h->m * 2 * TW, h->d_mask + (size_t)tile0 * h->E, post_g,  \
                        hard_g, done_g, skip_done, h->n, h->m, h->E, write_out)
         if (h->kn.rec_sc1) {
-            if (h->max_col_deg <= 16) VAR_REC_LAUNCH(16, true); else if (h->max_col_deg <= 32) VAR_REC_LAUNCH(32, true); else VAR_REC_LAUNCH(64, true);
+            if (h->max_col_deg <= 16) VAR_REC_LAUNCH(16, true); else VAR_REC_LAUNCH(32, true);
         } else {
-            if (h->max_col_deg <= 16) VAR_REC_LAUNCH(16, false); else if (h->max_col_deg <= 32) VAR_REC_LAUNCH(32, false); else VAR_REC_LAUNCH(64, false);
+            if (h->max_col_deg <= 16) VAR_REC_LAUNCH(16, false); else VAR_REC_LAUNCH(32, false);
         }
 #undef VAR_REC_LAUNCH
         LAUNCH_CHECK();

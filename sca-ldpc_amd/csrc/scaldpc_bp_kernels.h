@@ -1493,9 +1493,8 @@ __global__ __launch_bounds__(256) void k_var_rec(const int *__restrict__ list, c
 #define VR8(D) VR(D) VR(D + 1) VR(D + 2) VR(D + 3) VR(D + 4) VR(D + 5) VR(D + 6) VR(D + 7)
     switch (d) {
         VR(1) VR(2) VR(3) VR(4) VR(5) VR(6) VR(7)
-        VR8(8) VR8(16) VR8(24) VR8(32) VR8(40) VR8(48) VR8(56)
-        VR(64)
-        default: break;  // (degree 0: the posterior is the prior; degrees beyond 64 never reach this kernel)
+        VR8(8) VR8(16) VR8(24) VR(32)
+        default: break;  // (degree 0: the posterior is the prior; degrees beyond 32 never reach this kernel: rec_form())
     }
 #undef VR8
 #undef VR
