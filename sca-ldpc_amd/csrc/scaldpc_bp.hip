@@ -78,7 +78,6 @@ struct Knobs {
     int test_overlap = 0;     // early-exit tile groups: 1 = the convergence test of iteration it runs on a side stream beside the check pass of it + 1 (A/B knob: measured 3.4 % SLOWER on the config-5 sweep, profiles/r03/ab_test_overlap.log)
     int var_form = 1;         // k_var: 0 = ids fetched edge by edge, 1 = all ids up front as wide scalar loads (default)
     int rec_sc1 = 1;          // record form: message stores of the variable pass leave the XCD's L2 (sc1); 0 = plain stores (A/B knob)
-    int first_exact = 1;      // k_var_first as straight-line code for the column's exact degree (A/B knob; 0 = bucketed form)
     int minsum_rec = 1;       // min-sum on the tile kernels: check pass writes per-row records + lane masks instead of messages (k_check_minsum_rec / k_var_rec); 0 = message form
 };
 
@@ -238,7 +237,6 @@ bool set_knob(Knobs &k, const char *key, const char *val)
     else if (!strcmp(key, "first_fused")) k.first_fused = (int)x != 0;
     else if (!strcmp(key, "minsum_rec")) k.minsum_rec = (int)x != 0;
     else if (!strcmp(key, "rec_sc1")) k.rec_sc1 = (int)x != 0;
-    else if (!strcmp(key, "first_exact")) k.first_exact = (int)x != 0;
     else if (!strcmp(key, "fuse_test")) k.fuse_test = (int)x != 0;
     else return false;
     return true;
@@ -249,7 +247,7 @@ void knobs_from_env(Knobs &k)
     static const char *const names[][2] = {{"SCALDPC_PATH", "path"}, {"SCALDPC_SPLIT", "split"},
                                            {"SCALDPC_GROUP_MB", "group_mb"}, {"SCALDPC_EL_MAX", "el_max"},
                                            {"SCALDPC_EL_FUSE", "el_fuse"}, {"SCALDPC_COMPACT_AFTER", "compact_after"},
-                                           {"SCALDPC_VAR_ORDER", "var_order"}, {"SCALDPC_VAR_FORM", "var_form"}, {"SCALDPC_SPECULATE", "speculate"}, {"SCALDPC_FUSE_FINALIZE", "fuse_finalize"}, {"SCALDPC_TEST_OVERLAP", "test_overlap"}, {"SCALDPC_FIRST_FUSED", "first_fused"}, {"SCALDPC_FUSE_TEST", "fuse_test"}, {"SCALDPC_MINSUM_REC", "minsum_rec"}, {"SCALDPC_REC_SC1", "rec_sc1"}, {"SCALDPC_FIRST_EXACT", "first_exact"}};
+                                           {"SCALDPC_VAR_ORDER", "var_order"}, {"SCALDPC_VAR_FORM", "var_form"}, {"SCALDPC_SPECULATE", "speculate"}, {"SCALDPC_FUSE_FINALIZE", "fuse_finalize"}, {"SCALDPC_TEST_OVERLAP", "test_overlap"}, {"SCALDPC_FIRST_FUSED", "first_fused"}, {"SCALDPC_FUSE_TEST", "fuse_test"}, {"SCALDPC_MINSUM_REC", "minsum_rec"}, {"SCALDPC_REC_SC1", "rec_sc1"}};
     for (auto &nm : names)
         if (const char *e = getenv(nm[0])) (void)set_knob(k, nm[1], e);
     if (getenv("SCALDPC_MINSUM_LOOP")) k.minsum_loop = 1;  // presence switches it on, as before
@@ -817,14 +815,15 @@ int launch_var(scaldpc_bp *h, int G, float *post_g, u64 *hard_g, const u64 *done
     if (first_synd) {
         const int nrec = 4 * h->var_bk.blk[h->var_bk.nb];  // one record per wave of a plain k_var launch; two per wave here
         const dim3 grid2((unsigned)((nrec + 7) / 8), G);
-#define VAR_FIRST(CAP, X)                                                                                           \
-    hipLaunchKernelGGL((k_var_first<CAP, X>), grid2, dim3(256), 0, s, h->d_var_meta, h->d_csc_list, h->d_prior, msg0, post_g,  \
+#define VAR_FIRST(CAP)                                                                                              \
+    hipLaunchKernelGGL((k_var_first<CAP>), grid2, dim3(256), 0, s, h->d_var_meta, h->d_csc_list, h->d_prior, msg0, post_g,  \
                        hard_g, done_g, skip_done, h->n, h->E, write_out, (const int2 *)h->d_first_tab, first_synd, h->m, nrec)
-        if (h->kn.first_exact) {
-            if (h->max_col_deg <= 16) VAR_FIRST(16, true); else if (h->max_col_deg <= 32) VAR_FIRST(32, true); else VAR_FIRST(64, true);
-        } else {
-            if (h->max_col_deg <= 16) VAR_FIRST(16, false); else if (h->max_col_deg <= 32) VAR_FIRST(32, false); else VAR_FIRST(64, false);
-        }
+        if (h->max_col_deg <= 16)
+            VAR_FIRST(16);
+        else if (h->max_col_deg <= 32)
+            VAR_FIRST(32);
+        else
+            VAR_FIRST(64);
 #undef VAR_FIRST
         LAUNCH_CHECK();
         return 0;

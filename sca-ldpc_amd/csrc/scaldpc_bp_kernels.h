@@ -1201,47 +1201,6 @@ __device__ __forceinline__ float var_col_first(float *tile_base, unsigned lane, 
     return temp;
 }
 
-// The same pass as straight-line code for the column's EXACT degree (dispatched wave-uniformly), written for VALU
-// issue like the record-form kernels: the syndrome word of an edge's row is a wave-uniform lane mask and goes straight
-// into the select (message or its negation: XOR of the sign bit), the stores take the scalar-base form.  7 VALU
-// instructions per edge instead of ~16 plus the `k < d` predicates; same values, same order.
-template <int D>
-__device__ __forceinline__ float var_col_first_x(float *tile_base, unsigned lane, const int *__restrict__ rc,
-                                                 const int *__restrict__ ce1, int2 f, u64 wv, float pr)
-{
-    int eid[D];
-    {
-        const int4 *rec4 = (const int4 *)rc;
-        const int4 a = rec4[1], b = rec4[2], c = rec4[3], e = rec4[4];
-        const int in16[16] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, c.x, c.y, c.z, c.w, e.x, e.y, e.z, e.w};
-#pragma unroll
-        for (int k = 0; k < D && k < VAR_INLINE; k++) eid[k] = in16[k];
-#pragma unroll
-        for (int k = VAR_INLINE; k < D; k++) eid[k] = ce1[k];
-    }
-    float mm[D], pp[D];
-    const int wlo = (int)(unsigned)wv, whi = (int)(unsigned)(wv >> 32);
-#pragma unroll
-    for (int k = 0; k < D; k++) {
-        const u64 w = ((u64)(unsigned)__builtin_amdgcn_readlane(whi, k) << 32) | (unsigned)__builtin_amdgcn_readlane(wlo, k);
-        const float fk = __int_as_float(__builtin_amdgcn_readlane(f.x, k));
-        mm[k] = __builtin_amdgcn_inverse_ballot_w64(w) ? -fk : fk;
-    }
-    float temp = pr;
-#pragma unroll
-    for (int k = 0; k < D; k++) {
-        pp[k] = temp;
-        temp += mm[k];
-    }
-    float suf = 0.0f;
-#pragma unroll
-    for (int k = D - 1; k >= 0; k--) {
-        (sbase(tile_base + (size_t)rfl(eid[k]) * TW))[lane] = pp[k] + suf;
-        suf += mm[k];
-    }
-    return temp;
-}
-
 // first_tab[pos] = {first message of edge list[pos] (zero-syndrome codeword), its row}: one thread per list position.
 // The row of an edge = the last r with row_ptr[r] <= e (binary search).  grid ceil(E/256).
 __global__ __launch_bounds__(256) void k_first_tab(const int *__restrict__ list, const float *__restrict__ first_msg,
@@ -1355,7 +1314,7 @@ __global__ __launch_bounds__(256) void k_var(Buckets bk, const int *__restrict__
 // (one column per wave: 46.9 us per 128-codeword launch on the HQC-128 graph).  Every column of the graph has a
 // register-resident degree (the host checks: max column degree <= 64), records come in fours, hence in pairs.
 // grid (ceil(nrec / 8), G), block 256 = 4 waves = 8 records.
-template <int CAP, bool EXACT = false>
+template <int CAP>
 __global__ __launch_bounds__(256) void k_var_first(const int *__restrict__ list, const int *__restrict__ csc_edge,
                                                    const float *__restrict__ prior, float *msg, float *__restrict__ post,
                                                    u64 *__restrict__ hard, const u64 *__restrict__ done, int skip_done, int n,
@@ -1394,21 +1353,6 @@ __global__ __launch_bounds__(256) void k_var_first(const int *__restrict__ list,
         const int4 *r4 = (const int4 *)rec[j];
         const int *ce = csc_edge + cb[j];
         float L = pr[j];
-        if constexpr (EXACT) {
-#define VF(D)                                                                             \
-    case D:                                                                               \
-        if constexpr (D <= CAP) L = var_col_first_x<D>(tb, lane, rec[j], ce, f[j], wv[j], pr[j]); \
-        break;
-#define VF8(D) VF(D) VF(D + 1) VF(D + 2) VF(D + 3) VF(D + 4) VF(D + 5) VF(D + 6) VF(D + 7)
-            switch (d[j]) {
-                VF(1) VF(2) VF(3) VF(4) VF(5) VF(6) VF(7)
-                VF8(8) VF8(16) VF8(24) VF8(32) VF8(40) VF8(48) VF8(56)
-                VF(64)
-                default: break;
-            }
-#undef VF8
-#undef VF
-        } else
         switch (rec[j][3]) {
             case 1: L = var_col_first<1>(tb, lane, r4, ce, f[j], wv[j], d[j], pr[j]); break;
             case 2: L = var_col_first<2>(tb, lane, r4, ce, f[j], wv[j], d[j], pr[j]); break;
