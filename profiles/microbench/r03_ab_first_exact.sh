@@ -1,5 +1,6 @@
 #!/bin/bash
 # round 3 A/B: k_var_first as exact-degree straight-line code (SCALDPC_FIRST_EXACT=1) vs the bucketed form (=0)
+# (the knob SCALDPC_FIRST_EXACT existed only for this measurement: no gain, the variant was removed again)
 O=gpurun_out/r03ax; mkdir -p $O
 timeout -k 10 300 python -m pytest tests/test_bp_gpu.py -q -m gpu -x -p no:cacheprovider -k "first_iteration or riding or record_form or random_graph or infinite" > $O/pytest.log 2>&1; echo "pytest rc=$?"; tail -2 $O/pytest.log
 for V in 1 0 1 0; do

@@ -1,13 +1,23 @@
-// standalone comparison of the two row updates of k_check_minsum_rec (old: compare-select + per-lane state; new: scalar masks)
-#include <hip/hip_runtime.h>
+// The two row updates of the min-sum record form compared message for message: `row_old` below is the first version
+// (compare-select recurrences with per-lane state, ballots for the masks -- the recurrences of k_check_minsum_x word for
+// word), check_minsum_row_rec is the PRODUCT's (scaldpc_bp_kernels.h, included as it stands: scalar lane masks,
+// v_med3 / v_min on clamped magnitudes, inline-asm v_writelane).  Inputs full of ties, zeros, negative zeros, NaN,
+// +-inf and FLT_MAX, degrees 1 .. 64.  A difference is a bug: this program found the VALU-writes-SGPR ->
+// inline-asm v_writelane hazard on degree-1 rows.  Run by tests/test_bp_gpu.py::test_record_row_update_equivalence.
+// Build: make -C profiles/microbench rec_row_equivalence   (hipcc -O3 --offload-arch=gfx950 -ffp-contract=off)
+#include "../../sca-ldpc_amd/csrc/scaldpc_common.h"
+
 #include <cfloat>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <vector>
 typedef unsigned long long u64;
-constexpr int TW = 64;
-__device__ __forceinline__ int rfl(int x) { return __builtin_amdgcn_readfirstlane(x); }
+using namespace scaldpc;
+#include "../../sca-ldpc_amd/csrc/scaldpc_bp_kernels.h"
+
+namespace {
 template <int DEG, bool FIRST>
 __device__ __forceinline__ void row_old(const float *p, u64 synd_mask, float alpha, const float *__restrict__ prior,
                                                      const int *__restrict__ cidx, float *__restrict__ rec,
@@ -43,57 +53,13 @@ __device__ __forceinline__ void row_old(const float *p, u64 synd_mask, float alp
     if (lane < DEG) mask[lane] = make_ulonglong2(mneg, marg);
 }
 
-template <int DEG, bool FIRST>
-__device__ __forceinline__ void row_new(const float *p, u64 synd_mask, float alpha, const float *__restrict__ prior,
-                                                     const int *__restrict__ cidx, float *__restrict__ rec,
-                                                     float *__restrict__ rec2, ulonglong2 *__restrict__ mask, int lane)
-{
-    float x[DEG];
-#pragma unroll
-    for (int k = 0; k < DEG; k++) x[k] = FIRST ? prior[rfl(cidx[k])] : p[(size_t)k * TW];
-    float m1 = FLT_MAX, m2 = FLT_MAX;
-    const float fmax = FLT_MAX;
-    u64 par = ((u64)(unsigned)rfl((int)(synd_mask >> 32)) << 32) | (unsigned)rfl((int)synd_mask);  // (uniform by construction: keep it on the scalar side)
-#pragma unroll
-    for (int k = 0; k < DEG; k++) {
-        par ^= __ballot(x[k] <= 0.0f);
-        float a;
-        asm("v_min_f32 %0, |%1|, %2" : "=v"(a) : "v"(x[k]), "v"(fmax));
-        asm("v_med3_f32 %0, %1, %2, %0" : "+v"(m2) : "v"(a), "v"(m1));
-        asm("v_min_f32 %0, %0, %1" : "+v"(m1) : "v"(a));
-    }
-    rec[lane] = m1 * alpha;
-    rec2[lane] = m2 * alpha;
-    unsigned nlo = 0, nhi = 0, alo = 0, ahi = 0;  // lane k keeps edge k's two masks
-    // `found` starts as a zero the compiler cannot see through: every mask that reaches a v_writelane below is then the
-    // result of a SCALAR instruction (s_xor / s_andn2).  A v_writelane in inline asm that reads an SGPR the v_cmp right
-    // in front of it has just written gets the OLD value on gfx950 (the compiler's hazard recogniser pads its own
-    // instructions, not the inside of an asm statement): measured with edge 0's arg-min mask of degree-1 rows
-    // (profiles/microbench/rec_row_equivalence.hip).
-    u64 found;
-    asm volatile("s_mov_b64 %0, 0" : "=s"(found));
-#pragma unroll
-    for (int k = 0; k < DEG; k++) {
-        const u64 ng = __ballot(x[k] <= 0.0f) ^ par;
-        const u64 eq = __ballot(fabsf(x[k]) == m1);
-        const u64 ag = eq & ~found;
-        found |= eq;
-        asm("v_writelane_b32 %0, %1, %2" : "+v"(nlo) : "s"((unsigned)ng), "n"(k));
-        asm("v_writelane_b32 %0, %1, %2" : "+v"(nhi) : "s"((unsigned)(ng >> 32)), "n"(k));
-        asm("v_writelane_b32 %0, %1, %2" : "+v"(alo) : "s"((unsigned)ag), "n"(k));
-        asm("v_writelane_b32 %0, %1, %2" : "+v"(ahi) : "s"((unsigned)(ag >> 32)), "n"(k));
-    }
-    if (lane < DEG) mask[lane] = make_ulonglong2(((u64)nhi << 32) | nlo, ((u64)ahi << 32) | alo);
-}
-
-
 template <int DEG>
 __global__ void k(const float *msg, const u64 *synd, float alpha, float *recA, float *rec2A, ulonglong2 *maskA, float *recB, float *rec2B, ulonglong2 *maskB)
 {
     const int lane = threadIdx.x, r = blockIdx.x;
     const float *p = msg + (size_t)r * DEG * TW + lane;
     row_old<DEG, false>(p, synd[r], alpha, nullptr, nullptr, recA + r * TW, rec2A + r * TW, maskA + r * DEG, lane);
-    row_new<DEG, false>(p, synd[r], alpha, nullptr, nullptr, recB + r * TW, rec2B + r * TW, maskB + r * DEG, lane);
+    check_minsum_row_rec<DEG, false>(p, synd[r], alpha, nullptr, nullptr, recB + r * TW, rec2B + r * TW, maskB + r * DEG, lane);
 }
 template <int DEG>
 int run(int rows, unsigned seed)
@@ -140,6 +106,7 @@ int run(int rows, unsigned seed)
     printf("DEG %2d: %ld of %d messages differ, %ld records, %ld signs\n", DEG, bad, rows * TW * DEG, badrec, badneg);
     return bad != 0;
 }
+}  // namespace
 int main()
 {
     int rc = 0;

@@ -3,6 +3,7 @@ instantiation on the same seeded inputs.  Bit-exact for hard decisions,
 iteration counts and converged flags; min-sum posteriors bit-exact; tanh-rule
 posteriors within the fp32 tolerance written in tests/helpers.compare."""
 import importlib
+import os
 
 import numpy as np
 import pytest
@@ -413,6 +414,22 @@ def test_convergence_test_riding_on_the_check_pass_is_invisible(oracle, method):
         if graph is H or method == "min_sum":  # (tanh rule on the little dense graph: 40 iterations of non-settling BP amplify
             compare(outs[1][0], ref, method)   #  1-ulp differences beyond the fixed tolerance -- the property test's subject)
         assert len(np.unique(ref["iters"])) > 3  # a spread of iteration counts, so that latching at the right one matters
+
+
+def test_record_row_update_equivalence():
+    """The row update of the record-form check kernel (scalar lane masks, v_med3 / v_min on clamped magnitudes,
+    inline-asm v_writelane: `check_minsum_row_rec`, included from the product's header as it stands) against its first
+    version (the compare-select recurrences of k_check_minsum_x with per-lane state), message for message, on inputs full
+    of ties, zeros, negative zeros, NaN, +-inf and FLT_MAX, for degrees 1 ... 64.  The stand-alone program found the
+    VALU-writes-SGPR -> inline-asm v_writelane hazard on degree-1 rows; it is built by __graft_entry__.build()."""
+    import subprocess
+
+    d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "microbench")
+    subprocess.check_call(["make", "-C", d, "rec_row_equivalence"], stdout=subprocess.DEVNULL)  # (no-op when it is up to date)
+    r = subprocess.run([os.path.join(d, "rec_row_equivalence")], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("DEG")]
+    assert len(lines) == 12 and all(" 0 of " in ln and " 0 records" in ln and " 0 signs" in ln for ln in lines), r.stdout
 
 
 def test_minsum_record_form_is_invisible(oracle):
