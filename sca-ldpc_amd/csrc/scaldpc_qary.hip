@@ -357,7 +357,95 @@ struct QEnum {
         (QEnum<Q, K, J + 1, D..., Qs>::run(A, Bt, S + A[J][Qs], nconf), ...);
     }
 };
-// last edge: its digit is fixed by sum d = 0
+// min of three in ONE instruction (v_min3_f32 = v_min_f32 of v_min_f32: a quiet NaN operand is ignored, as in vmin)
+__device__ __forceinline__ float vmin3(float a, float b, float c)
+{
+    float r;
+    asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+
+// Last FREE digit (edge K-2; edge K-1's digit then follows from sum d = 0): the up to Q assignments that differ only in
+// these two digits share the digit of every earlier edge j, i.e. they all lower the SAME beta[j][d_j].  Their candidates
+// S2_q - alpha[j][d_j] (each S2_q built left to right as before: the reference's additions in the reference's order) are
+// folded into that minimum two at a time with v_min3_f32 -- min is exact and order-free, so the values are those of
+// one v_min per candidate, with a third fewer instructions on the K - 2 shared edges.
+template <int Q, int K, int... D>
+struct QEnum<Q, K, K - 2, D...> {
+    static_assert(sizeof...(D) == K - 2, "digits of the edges before the last free one");
+    static constexpr int B = (Q - 1) / 2;
+    static constexpr int base = -((D - B) + ... + 0);
+    static constexpr int dl(int q) { return base - (q - B); }           // digit of the last edge when edge K-2 takes q
+    static constexpr bool ok(int q) { return dl(q) >= -B && dl(q) <= B; }
+    static constexpr int nvalid()
+    {
+        int n = 0;
+        for (int q = 0; q < Q; q++) n += ok(q) ? 1 : 0;
+        return n;
+    }
+    static __device__ __forceinline__ void run(const float (&A)[K][Q], float (&Bt)[K][Q], float S, int &nconf)
+    {
+        constexpr int NV = nvalid();
+        if constexpr (NV > 0) {
+            float S2[NV];
+            fill(A, Bt, S, nconf, S2, std::make_integer_sequence<int, Q>());
+            shared(A, Bt, S2, std::make_integer_sequence<int, K - 2>());
+        }
+    }
+    // valid q -> its slot among the valid ones
+    static constexpr int slot(int q)
+    {
+        int n = 0;
+        for (int t = 0; t < q; t++) n += ok(t) ? 1 : 0;
+        return n;
+    }
+    template <int... Qs>
+    static __device__ __forceinline__ void fill(const float (&A)[K][Q], float (&Bt)[K][Q], float S, int &nconf, float (&S2)[nvalid()],
+                                                std::integer_sequence<int, Qs...>)
+    {
+        (one<Qs>(A, Bt, S, nconf, S2), ...);
+    }
+    template <int q>
+    static __device__ __forceinline__ void one(const float (&A)[K][Q], float (&Bt)[K][Q], float S, int &nconf, float (&S2)[nvalid()])
+    {
+        if constexpr (ok(q)) {
+            constexpr int ql = dl(q) + B;
+            const float s2 = (S + A[K - 2][q]) + A[K - 1][ql];
+            S2[slot(q)] = s2;
+            nconf += finite_f(s2) ? 1 : 0;
+            Bt[K - 2][q] = vmin(s2 - A[K - 2][q], Bt[K - 2][q]);    // these two digits are the assignment's own
+            Bt[K - 1][ql] = vmin(s2 - A[K - 1][ql], Bt[K - 1][ql]);
+        }
+    }
+    template <int... Js>
+    static __device__ __forceinline__ void shared(const float (&A)[K][Q], float (&Bt)[K][Q], const float (&S2)[nvalid()],
+                                                  std::integer_sequence<int, Js...>)
+    {
+        constexpr int dig[sizeof...(D) + 1] = {D..., 0};
+        (edge<Js, dig[Js]>(A, Bt, S2), ...);
+    }
+    template <int j, int dj>
+    static __device__ __forceinline__ void edge(const float (&A)[K][Q], float (&Bt)[K][Q], const float (&S2)[nvalid()])
+    {
+        constexpr int NV = nvalid();
+        float m = Bt[j][dj];
+        const float a = A[j][dj];
+        if constexpr (NV == 1) {
+            m = vmin(S2[0] - a, m);
+        } else if constexpr (NV == 2) {
+            m = vmin3(S2[0] - a, S2[1] - a, m);
+        } else if constexpr (NV == 3) {
+            m = vmin(S2[2] - a, vmin3(S2[0] - a, S2[1] - a, m));
+        } else if constexpr (NV == 4) {
+            m = vmin3(S2[2] - a, S2[3] - a, vmin3(S2[0] - a, S2[1] - a, m));
+        } else {
+            static_assert(NV == 5, "alphabets of up to 5 symbols are compiled (Q = 3, 5)");
+            m = vmin(S2[4] - a, vmin3(S2[2] - a, S2[3] - a, vmin3(S2[0] - a, S2[1] - a, m)));
+        }
+        Bt[j][dj] = m;
+    }
+};
+// last edge: its digit is fixed by sum d = 0 (reached directly only when K = 1)
 template <int Q, int K, int... D>
 struct QEnum<Q, K, K - 1, D...> {
     static constexpr int B = (Q - 1) / 2;
