@@ -425,8 +425,11 @@ def test_record_row_update_equivalence():
     import subprocess
 
     d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "microbench")
-    subprocess.check_call(["make", "-C", d, "rec_row_equivalence"], stdout=subprocess.DEVNULL)  # (no-op when it is up to date)
-    r = subprocess.run([os.path.join(d, "rec_row_equivalence")], capture_output=True, text=True, timeout=120)
+    exe = os.path.join(d, "rec_row_equivalence")
+    made = subprocess.run(["make", "-C", d, "rec_row_equivalence"], capture_output=True, text=True)  # (no-op when up to date)
+    if made.returncode != 0 and not os.path.exists(exe):
+        pytest.fail("rec_row_equivalence is not built and cannot be built here:\n" + made.stdout + made.stderr)
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stdout + r.stderr
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("DEG")]
     assert len(lines) == 12 and all(" 0 of " in ln and " 0 records" in ln and " 0 signs" in ln for ln in lines), r.stdout
