@@ -206,6 +206,10 @@ int scaldpc_bp_last_stats(scaldpc_bp *h, int64_t *out);
  *                   row and codeword, the two magnitudes a min-sum check sends (8 B) and, per edge and tile, two lane
  *                   masks (sign, arg-min: 0.25 B per codeword) instead of 4 B per edge and codeword; the variable pass
  *                   rebuilds every message from them, bit for bit.  0 = messages both ways.  (SCALDPC_MINSUM_REC)
+ *   "rec_skip1"     1 (default) = in the record form a variable pass WITHOUT output (fixed-iteration runs, every pass but
+ *                   the first and the last) leaves out the columns of degree <= 1: such a column always sends its prior,
+ *                   iteration 1 has written it into the message array and the record check pass never overwrites it
+ *                   (the identity block of an HQC graph: 4000 of 21669 column waves per tile).  0 = all columns (A/B).
  *   "rec_sc1"       1 (default) = the record form's variable pass stores its messages with sc1 (the line leaves the
  *                   XCD's L2, which keeps it for the row records); 0 = plain stores (A/B).  (SCALDPC_REC_SC1)
  *   "first_fused"   1 (default) = iteration 1 of the tile kernels runs without its check pass: the first variable

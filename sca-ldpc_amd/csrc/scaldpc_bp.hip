@@ -78,6 +78,7 @@ struct Knobs {
     int test_overlap = 0;     // early-exit tile groups: 1 = the convergence test of iteration it runs on a side stream beside the check pass of it + 1 (A/B knob: measured 3.4 % SLOWER on the config-5 sweep, profiles/r03/ab_test_overlap.log)
     int var_form = 1;         // k_var: 0 = ids fetched edge by edge, 1 = all ids up front as wide scalar loads (default)
     int rec_sc1 = 1;          // record form: message stores of the variable pass leave the XCD's L2 (sc1); 0 = plain stores (A/B knob)
+    int rec_skip1 = 1;        // record form: passes without output leave out the columns of degree <= 1 (their message is the prior, written once by iteration 1; the record check pass never overwrites it); 0 = all columns every pass (A/B knob)
     int minsum_rec = 1;       // min-sum on the tile kernels: check pass writes per-row records + lane masks instead of messages (k_check_minsum_rec / k_var_rec); 0 = message form
 };
 
@@ -181,6 +182,7 @@ struct scaldpc_bp {
     ulonglong2 *d_mask = nullptr;
     int cap_rec_group = 0;
     int *d_csc_row = nullptr, *d_var_rows = nullptr;
+    bool var_reversed = false;  // the column records are laid out heaviest first (var_order bit 1): the degree-1 bucket is at the END
     bool first_valid = false;
     int first_method = -1;
     float first_alpha = 0.0f;
@@ -237,6 +239,7 @@ bool set_knob(Knobs &k, const char *key, const char *val)
     else if (!strcmp(key, "first_fused")) k.first_fused = (int)x != 0;
     else if (!strcmp(key, "minsum_rec")) k.minsum_rec = (int)x != 0;
     else if (!strcmp(key, "rec_sc1")) k.rec_sc1 = (int)x != 0;
+    else if (!strcmp(key, "rec_skip1")) k.rec_skip1 = (int)x != 0;
     else if (!strcmp(key, "fuse_test")) k.fuse_test = (int)x != 0;
     else return false;
     return true;
@@ -247,7 +250,7 @@ void knobs_from_env(Knobs &k)
     static const char *const names[][2] = {{"SCALDPC_PATH", "path"}, {"SCALDPC_SPLIT", "split"},
                                            {"SCALDPC_GROUP_MB", "group_mb"}, {"SCALDPC_EL_MAX", "el_max"},
                                            {"SCALDPC_EL_FUSE", "el_fuse"}, {"SCALDPC_COMPACT_AFTER", "compact_after"},
-                                           {"SCALDPC_VAR_ORDER", "var_order"}, {"SCALDPC_VAR_FORM", "var_form"}, {"SCALDPC_SPECULATE", "speculate"}, {"SCALDPC_FUSE_FINALIZE", "fuse_finalize"}, {"SCALDPC_TEST_OVERLAP", "test_overlap"}, {"SCALDPC_FIRST_FUSED", "first_fused"}, {"SCALDPC_FUSE_TEST", "fuse_test"}, {"SCALDPC_MINSUM_REC", "minsum_rec"}, {"SCALDPC_REC_SC1", "rec_sc1"}};
+                                           {"SCALDPC_VAR_ORDER", "var_order"}, {"SCALDPC_VAR_FORM", "var_form"}, {"SCALDPC_SPECULATE", "speculate"}, {"SCALDPC_FUSE_FINALIZE", "fuse_finalize"}, {"SCALDPC_TEST_OVERLAP", "test_overlap"}, {"SCALDPC_FIRST_FUSED", "first_fused"}, {"SCALDPC_FUSE_TEST", "fuse_test"}, {"SCALDPC_MINSUM_REC", "minsum_rec"}, {"SCALDPC_REC_SC1", "rec_sc1"}, {"SCALDPC_REC_SKIP1", "rec_skip1"}};
     for (auto &nm : names)
         if (const char *e = getenv(nm[0])) (void)set_knob(k, nm[1], e);
     if (getenv("SCALDPC_MINSUM_LOOP")) k.minsum_loop = 1;  // presence switches it on, as before
@@ -485,6 +488,7 @@ int ensure_tile_tables(scaldpc_bp *h)
             pos += d;
         }
     }
+    h->var_reversed = (var_order & 2) != 0;
     if (var_order & 2) {
         // heaviest columns FIRST: the waves that start last are then the cheapest ones (degree-1 identity
         // columns), which shortens the tail of the launch (longest-processing-time-first)
@@ -807,7 +811,7 @@ int ensure_first_table(scaldpc_bp *h, int method, float alpha1, hipStream_t s)
 
 // first_synd: non-null = iteration 1 without its check pass (the group's syndrome planes; ensure_first_table first)
 int launch_var(scaldpc_bp *h, int G, float *post_g, u64 *hard_g, const u64 *done_g, int skip_done, int write_out,
-               hipStream_t s, int tile0 = 0, const u64 *first_synd = nullptr, bool rec = false)
+               hipStream_t s, int tile0 = 0, const u64 *first_synd = nullptr, bool rec = false, bool light = false)
 {
     dim3 grid(h->var_bk.blk[h->var_bk.nb], G);
     float *const msg0 = h->d_msg + (size_t)tile0 * h->E * TW;
@@ -829,10 +833,18 @@ int launch_var(scaldpc_bp *h, int G, float *post_g, u64 *hard_g, const u64 *done
         return 0;
     }
     if (rec) {  // the check pass left records, not messages (rec_form)
+        // light: a pass without output after iteration 1.  A column of degree <= 1 always sends its prior; iteration 1
+        // has written that into the message array and the record check pass never overwrites it, so such a pass has
+        // nothing to do for the first bucket (the identity block of an HQC graph: 4000 of 21669 column waves per tile).
+        const int nblk = h->var_bk.blk[h->var_bk.nb];
+        const int n1 = (h->var_bk.nb > 0 && h->var_bk.maxd[0] == 1) ? h->var_bk.blk[1] : 0;
+        const bool slim = light && !write_out && h->kn.rec_skip1 && n1 > 0 && n1 < nblk;
+        const dim3 gridr((unsigned)(slim ? nblk - n1 : nblk), G);
+        const int blk0 = slim && !h->var_reversed ? n1 : 0;
 #define VAR_REC_LAUNCH(CAP, S1)                                                                                     \
-    hipLaunchKernelGGL((k_var_rec<CAP, S1>), grid, dim3(256), 0, s, h->d_var_meta, h->d_var_rows, h->d_csc_list, h->d_csc_row, \
+    hipLaunchKernelGGL((k_var_rec<CAP, S1>), gridr, dim3(256), 0, s, h->d_var_meta, h->d_var_rows, h->d_csc_list, h->d_csc_row, \
                        h->d_prior, msg0, h->d_rec + (size_t)tile0 * h->m * 2 * TW, h->d_mask + (size_t)tile0 * h->E, post_g,  \
-                       hard_g, done_g, skip_done, h->n, h->m, h->E, write_out)
+                       hard_g, done_g, skip_done, h->n, h->m, h->E, write_out, blk0)
         if (h->kn.rec_sc1) {
             if (h->max_col_deg <= 16) VAR_REC_LAUNCH(16, true); else VAR_REC_LAUNCH(32, true);
         } else {
@@ -1115,7 +1127,7 @@ int iterate_tiles(scaldpc_bp *h, const TileState &st, int g0, int g, int max_ite
             SC_TRY(wait_test(k));  // the test of the previous iteration decides which codewords this pass may still write
             SC_TRY(launch_var(h, gs[k], st.post ? st.post + (size_t)ta * h->n * TW : nullptr, st.hard + (size_t)ta * h->n,
                               st.done + ta, skip, (early || last) ? 1 : 0, lane[k], t0[k],
-                              no_check ? st.synd + (size_t)ta * h->m : nullptr, !no_check && rec_form(h, method)));
+                              no_check ? st.synd + (size_t)ta * h->m : nullptr, !no_check && rec_form(h, method), it > 1));
             if (ride && !last && !poll) {
                 verdict_pending[k] = true;  // the next check pass of this lane carries the test
             } else if ((early || last) && h->kn.fuse_finalize) {  // convergence test + latch, one launch
@@ -2297,7 +2309,7 @@ int scaldpc_bp_time_kernels(scaldpc_bp *h, int32_t iters, int32_t method, float 
         for (int it = 0; it < iters && !rc; it++) rc = launch_check(h, method, alpha_for(alpha, it + 1), g, h->d_synd, h->d_done, 0, s);
         SC_HIP(hipEventRecord(ev[1], s));
         SC_HIP(hipEventRecord(ev[2], s));
-        for (int it = 0; it < iters && !rc; it++) rc = launch_var(h, g, nullptr, h->d_hard, h->d_done, 0, 0, s, 0, nullptr, rec_form(h, method));
+        for (int it = 0; it < iters && !rc; it++) rc = launch_var(h, g, nullptr, h->d_hard, h->d_done, 0, 0, s, 0, nullptr, rec_form(h, method), true);
         SC_HIP(hipEventRecord(ev[3], s));
         if (!rc) SC_HIP(hipStreamSynchronize(s));
         if (!rc) {
@@ -2331,7 +2343,7 @@ int scaldpc_bp_time_kernels(scaldpc_bp *h, int32_t iters, int32_t method, float 
             }
             for (int k = 0; k < 2 && !rc; k++) {
                 rc = launch_var(h, gs[k], nullptr, h->d_hard + (size_t)t0[k] * h->n, h->d_done + t0[k], 0, 0, lane[k], t0[k], nullptr,
-                                rec_form(h, method));
+                                rec_form(h, method), true);
                 SC_HIP(hipEventRecord(M(k, 2 * it + 2), lane[k]));
             }
         }

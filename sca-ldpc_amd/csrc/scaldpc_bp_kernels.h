@@ -1467,11 +1467,11 @@ __global__ __launch_bounds__(256) void k_var_rec(const int *__restrict__ list, c
                                                  const float *__restrict__ prior, float *msg, const float *__restrict__ rec,
                                                  const ulonglong2 *__restrict__ mask, float *__restrict__ post,
                                                  u64 *__restrict__ hard, const u64 *__restrict__ done, int skip_done, int n, int m,
-                                                 long E, int write_out)
+                                                 long E, int write_out, int blk0)
 {
     const unsigned lane = threadIdx.x & 63u;
     const int tl = blockIdx.y;
-    const int ri = rfl((int)blockIdx.x * 4 + (int)(threadIdx.x >> 6));
+    const int ri = rfl(((int)blockIdx.x + blk0) * 4 + (int)(threadIdx.x >> 6));  // blk0: first block of the launch's slice of the records
     const int *rc = list + (size_t)ri * VAR_REC;
     const u64 dn = done[tl];
     if (skip_done && dn == ~0ull) return;
