@@ -152,7 +152,10 @@ int scaldpc_bp_decode_batch(scaldpc_bp *h, const uint8_t *in, int32_t input_kind
  *   launches[3]     lanes: 1 = the series ran one after the other over the whole tile group;
  *                   2 = the decode's two-stream schedule: the check series over the first
  *                   lane's tiles and the variable series over the second lane's tiles ran
- *                   concurrently, as they do in a decode's steady state
+ *                   concurrently, as they do in a decode's steady state.  There every launch is followed by an
+ *                   event (its duration = the distance to the previous event on its lane); because those events
+ *                   cost the schedule its back-to-back dispatch, the same launch pattern is run once more WITHOUT
+ *                   them, bracketed per lane, and ms[0] / ms[1] are scaled so that check + variable = the true pair
  *   launches[4]     codewords swept per variable launch;  launches[5] = 1 if min-sum ran in
  *                   its record form (k_check_minsum_rec / k_var_rec; knob "minsum_rec"), else 0
  */
