@@ -209,6 +209,9 @@ int scaldpc_bp_last_stats(scaldpc_bp *h, int64_t *out);
  *                   row and codeword, the two magnitudes a min-sum check sends (8 B) and, per edge and tile, two lane
  *                   masks (sign, arg-min: 0.25 B per codeword) instead of 4 B per edge and codeword; the variable pass
  *                   rebuilds every message from them, bit for bit.  0 = messages both ways.  (SCALDPC_MINSUM_REC)
+ *   "rec_maskpos"   1 (default) = the record form's lane masks are laid out by POSITION in the variable pass's edge order
+ *                   (a column's masks contiguous: its gather becomes one coalesced load; the check pass scatters its
+ *                   16-B stores instead); 0 = by edge id (A/B).  (SCALDPC_REC_MASKPOS)
  *   "rec_skip1"     1 (default) = in the record form a variable pass WITHOUT output (fixed-iteration runs, every pass but
  *                   the first and the last) leaves out the columns of degree <= 1: such a column always sends its prior,
  *                   iteration 1 has written it into the message array and the record check pass never overwrites it

@@ -78,6 +78,7 @@ struct Knobs {
     int test_overlap = 0;     // early-exit tile groups: 1 = the convergence test of iteration it runs on a side stream beside the check pass of it + 1 (A/B knob: measured 3.4 % SLOWER on the config-5 sweep, profiles/r03/ab_test_overlap.log)
     int var_form = 1;         // k_var: 0 = ids fetched edge by edge, 1 = all ids up front as wide scalar loads (default)
     int rec_sc1 = 1;          // record form: message stores of the variable pass leave the XCD's L2 (sc1); 0 = plain stores (A/B knob)
+    int rec_maskpos = 1;      // record form: lane masks laid out by position in the re-laid edge list (a column's masks contiguous for the variable pass; scattered 16-B stores in the check pass); 0 = by edge id (A/B knob)
     int rec_skip1 = 1;        // record form: passes without output leave out the columns of degree <= 1 (their message is the prior, written once by iteration 1; the record check pass never overwrites it); 0 = all columns every pass (A/B knob)
     int minsum_rec = 1;       // min-sum on the tile kernels: check pass writes per-row records + lane masks instead of messages (k_check_minsum_rec / k_var_rec); 0 = message form
 };
@@ -181,7 +182,7 @@ struct scaldpc_bp {
     float *d_rec = nullptr;
     ulonglong2 *d_mask = nullptr;
     int cap_rec_group = 0;
-    int *d_csc_row = nullptr, *d_var_rows = nullptr;
+    int *d_csc_row = nullptr, *d_var_rows = nullptr, *d_csr_pos = nullptr;
     bool var_reversed = false;  // the column records are laid out heaviest first (var_order bit 1): the degree-1 bucket is at the END
     bool first_valid = false;
     int first_method = -1;
@@ -240,6 +241,7 @@ bool set_knob(Knobs &k, const char *key, const char *val)
     else if (!strcmp(key, "minsum_rec")) k.minsum_rec = (int)x != 0;
     else if (!strcmp(key, "rec_sc1")) k.rec_sc1 = (int)x != 0;
     else if (!strcmp(key, "rec_skip1")) k.rec_skip1 = (int)x != 0;
+    else if (!strcmp(key, "rec_maskpos")) k.rec_maskpos = (int)x != 0;
     else if (!strcmp(key, "fuse_test")) k.fuse_test = (int)x != 0;
     else return false;
     return true;
@@ -250,7 +252,7 @@ void knobs_from_env(Knobs &k)
     static const char *const names[][2] = {{"SCALDPC_PATH", "path"}, {"SCALDPC_SPLIT", "split"},
                                            {"SCALDPC_GROUP_MB", "group_mb"}, {"SCALDPC_EL_MAX", "el_max"},
                                            {"SCALDPC_EL_FUSE", "el_fuse"}, {"SCALDPC_COMPACT_AFTER", "compact_after"},
-                                           {"SCALDPC_VAR_ORDER", "var_order"}, {"SCALDPC_VAR_FORM", "var_form"}, {"SCALDPC_SPECULATE", "speculate"}, {"SCALDPC_FUSE_FINALIZE", "fuse_finalize"}, {"SCALDPC_TEST_OVERLAP", "test_overlap"}, {"SCALDPC_FIRST_FUSED", "first_fused"}, {"SCALDPC_FUSE_TEST", "fuse_test"}, {"SCALDPC_MINSUM_REC", "minsum_rec"}, {"SCALDPC_REC_SC1", "rec_sc1"}, {"SCALDPC_REC_SKIP1", "rec_skip1"}};
+                                           {"SCALDPC_VAR_ORDER", "var_order"}, {"SCALDPC_VAR_FORM", "var_form"}, {"SCALDPC_SPECULATE", "speculate"}, {"SCALDPC_FUSE_FINALIZE", "fuse_finalize"}, {"SCALDPC_TEST_OVERLAP", "test_overlap"}, {"SCALDPC_FIRST_FUSED", "first_fused"}, {"SCALDPC_FUSE_TEST", "fuse_test"}, {"SCALDPC_MINSUM_REC", "minsum_rec"}, {"SCALDPC_REC_SC1", "rec_sc1"}, {"SCALDPC_REC_SKIP1", "rec_skip1"}, {"SCALDPC_REC_MASKPOS", "rec_maskpos"}};
     for (auto &nm : names)
         if (const char *e = getenv(nm[0])) (void)set_knob(k, nm[1], e);
     if (getenv("SCALDPC_MINSUM_LOOP")) k.minsum_loop = 1;  // presence switches it on, as before
@@ -417,6 +419,7 @@ int ensure_tile_tables(scaldpc_bp *h)
     const size_t o_var_meta = reserve((size_t)4 * VAR_REC * hv.bk.blk[hv.bk.nb] + 4), o_csc_list = reserve((size_t)h->E + 1 + 64);
     const size_t o_row_list = reserve((size_t)16 * hr.bk.blk[hr.bk.nb] + 4);
     const size_t o_csc_row = reserve((size_t)h->E + 1 + 64);
+    const size_t o_csr_pos = reserve((size_t)h->E + 64);  // position of every CSR edge in the re-laid list
     const size_t o_var_rows = reserve((size_t)4 * VAR_INLINE * hv.bk.blk[hv.bk.nb] + 4);  // rows of the records' inline edges
     int *host = stage_buffer(total);
     if (!host) return fail(SCALDPC_ENOMEM, "out of host memory");
@@ -482,6 +485,7 @@ int ensure_tile_tables(scaldpc_bp *h)
             for (int k = 0; k < d; k++) {
                 relaid[pos + k] = csc_edge[(size_t)col_ptr[v] + k];
                 relaid_row[pos + k] = edge_row[relaid[pos + k]];
+                host[o_csr_pos + relaid[pos + k]] = pos + k;
             }
             for (int k = 0; k < VAR_INLINE; k++) md[4 + k] = k < d ? relaid[pos + k] : 0;
             for (int k = 0; k < VAR_INLINE; k++) mr[k] = k < d ? relaid_row[pos + k] : 0;
@@ -506,6 +510,7 @@ int ensure_tile_tables(scaldpc_bp *h)
     h->d_row_list = h->d_tile_tab + o_row_list;
     h->d_csc_row = h->d_tile_tab + o_csc_row;
     h->d_var_rows = h->d_tile_tab + o_var_rows;
+    h->d_csr_pos = h->d_tile_tab + o_csr_pos;
     return 0;
 }
 
@@ -692,10 +697,10 @@ int launch_check(scaldpc_bp *h, int method, float alpha, int G, const u64 *synd_
             ulonglong2 *const mask0 = h->d_mask + (size_t)tile0 * h->E;
 #define MSR_LAUNCH(CAP, F)                                                                                          \
     hipLaunchKernelGGL((k_check_minsum_rec<CAP, F>), gridx, dim3(256), 0, s, h->d_row_list, msg0, synd_g, done_g, skip_done, \
-                       h->m, h->E, alpha, h->d_col_idx, h->d_prior, rec0, mask0)
+                       h->m, h->E, alpha, h->d_col_idx, h->d_prior, rec0, mask0, h->kn.rec_maskpos ? h->d_csr_pos : nullptr)
 #define MSR_PAR(CAP)                                                                                                \
     hipLaunchKernelGGL((k_check_minsum_rec<CAP, false, true>), gridx, dim3(256), 0, s, h->d_row_list, msg0, synd_g, done_g, \
-                       skip_done, h->m, h->E, alpha, h->d_col_idx, h->d_prior, rec0, mask0, *ft)
+                       skip_done, h->m, h->E, alpha, h->d_col_idx, h->d_prior, rec0, mask0, h->kn.rec_maskpos ? h->d_csr_pos : nullptr, *ft)
             if (ft && !first) {
                 if (h->max_row_deg <= 16) MSR_PAR(16); else if (h->max_row_deg <= 32) MSR_PAR(32); else MSR_PAR(64);
             } else if (h->max_row_deg <= 16) {
@@ -844,7 +849,7 @@ int launch_var(scaldpc_bp *h, int G, float *post_g, u64 *hard_g, const u64 *done
 #define VAR_REC_LAUNCH(CAP, S1)                                                                                     \
     hipLaunchKernelGGL((k_var_rec<CAP, S1>), gridr, dim3(256), 0, s, h->d_var_meta, h->d_var_rows, h->d_csc_list, h->d_csc_row, \
                        h->d_prior, msg0, h->d_rec + (size_t)tile0 * h->m * 2 * TW, h->d_mask + (size_t)tile0 * h->E, post_g,  \
-                       hard_g, done_g, skip_done, h->n, h->m, h->E, write_out, blk0)
+                       hard_g, done_g, skip_done, h->n, h->m, h->E, write_out, blk0, h->kn.rec_maskpos)
         if (h->kn.rec_sc1) {
             if (h->max_col_deg <= 16) VAR_REC_LAUNCH(16, true); else VAR_REC_LAUNCH(32, true);
         } else {

@@ -652,8 +652,13 @@ __global__ __launch_bounds__(256) void k_check_minsum_x(const int *__restrict__ 
 template <int DEG, bool FIRST>
 __device__ __forceinline__ void check_minsum_row_rec(const float *p, u64 synd_mask, float alpha, const float *__restrict__ prior,
                                                      const int *__restrict__ cidx, float *__restrict__ rec,
-                                                     float *__restrict__ rec2, ulonglong2 *__restrict__ mask, int lane)
+                                                     float *__restrict__ rec2, ulonglong2 *__restrict__ mask, int lane,
+                                                     const int *__restrict__ pos)
 {
+    // pos != nullptr: the masks are laid out in the variable pass's order (position of the edge in the re-laid edge list:
+    // a column's masks are contiguous there); lane k fetches edge k's position up front
+    int mp = lane;
+    if (pos && lane < DEG) mp = pos[lane];
     float x[DEG];
 #pragma unroll
     for (int k = 0; k < DEG; k++) x[k] = FIRST ? prior[rfl(cidx[k])] : p[(size_t)k * TW];
@@ -689,7 +694,7 @@ __device__ __forceinline__ void check_minsum_row_rec(const float *p, u64 synd_ma
         asm("v_writelane_b32 %0, %1, %2" : "+v"(alo) : "s"((unsigned)ag), "n"(k));
         asm("v_writelane_b32 %0, %1, %2" : "+v"(ahi) : "s"((unsigned)(ag >> 32)), "n"(k));
     }
-    if (lane < DEG) mask[lane] = make_ulonglong2(((u64)nhi << 32) | nlo, ((u64)ahi << 32) | alo);
+    if (lane < DEG) mask[mp] = make_ulonglong2(((u64)nhi << 32) | nlo, ((u64)ahi << 32) | alo);
 }
 
 template <int CAP, bool FIRST, bool PAR = false>
@@ -698,7 +703,7 @@ __global__ __launch_bounds__(256) void k_check_minsum_rec(const int *__restrict_
                                                           int skip_done, int m, long E, float alpha,
                                                           const int *__restrict__ col_idx, const float *__restrict__ prior,
                                                           float *__restrict__ rec, ulonglong2 *__restrict__ mask,
-                                                          FusedTest ft = FusedTest{})
+                                                          const int *__restrict__ csr_pos, FusedTest ft = FusedTest{})
 {
     const int lane = threadIdx.x & 63;
     const int tl = blockIdx.y;
@@ -719,11 +724,12 @@ __global__ __launch_bounds__(256) void k_check_minsum_rec(const int *__restrict_
         const int deg = md[2];
         const float *p = msg + ((size_t)tl * E + e0) * TW + lane;
         float *rc = rec + ((size_t)tl * 2 * m + r) * TW, *rc2 = rc + (size_t)m * TW;  // two planes per tile: [m1 | m2][row][64]
-        ulonglong2 *mk = mask + (size_t)tl * E + e0;
+        ulonglong2 *mk = mask + (size_t)tl * E + (csr_pos ? 0 : e0);  // (by position: the tile's base; by edge: the row's first)
+        const int *ps = csr_pos ? csr_pos + e0 : nullptr;
         const u64 sw = synd[(size_t)tl * m + r];  // (uniform: a scalar load; the row's syndrome bits ARE a lane mask)
 #define MR(D)                                                                                                       \
     case D:                                                                                                         \
-        if constexpr (D <= CAP) check_minsum_row_rec<D, FIRST>(p, sw, alpha, prior, col_idx + e0, rc, rc2, mk, lane);    \
+        if constexpr (D <= CAP) check_minsum_row_rec<D, FIRST>(p, sw, alpha, prior, col_idx + e0, rc, rc2, mk, lane, ps); \
         break;
 #define MR8(D) MR(D) MR(D + 1) MR(D + 2) MR(D + 3) MR(D + 4) MR(D + 5) MR(D + 6) MR(D + 7)
         switch (deg) {
@@ -1394,7 +1400,7 @@ template <int D, bool SC1>
 __device__ __forceinline__ float var_col_rec(float *tile_base, const float *__restrict__ rec_base,
                                              const float *__restrict__ rec2_base, const ulonglong2 *__restrict__ mask_tile,
                                              unsigned lane, const int *__restrict__ rc, const int4 *__restrict__ row4,
-                                             const int *__restrict__ ce1, const int *__restrict__ cr1, float pr)
+                                             const int *__restrict__ ce1, const int *__restrict__ cr1, float pr, int mask_by_pos)
 {
     int eid[D], rid[D];
     {
@@ -1414,14 +1420,19 @@ __device__ __forceinline__ float var_col_rec(float *tile_base, const float *__re
             rid[k] = cr1[k];
         }
     }
-    // lane j's edge id, then its two masks
-    int ej = 0;
-#pragma unroll
-    for (int k = 0; k < D && k < VAR_INLINE; k++) asm("v_writelane_b32 %0, %1, %2" : "+v"(ej) : "s"(eid[k]), "n"(k));
-    if constexpr (D > VAR_INLINE)
-        if ((int)lane >= VAR_INLINE && (int)lane < D) ej = ce1[lane];
+    // lane j's two masks: by position (mask_by_pos = the column's first position + 1: contiguous, no edge id needed) or by
+    // edge id (put into the lane with v_writelane)
     ulonglong2 mk = make_ulonglong2(0, 0);
-    if ((int)lane < D) mk = mask_tile[ej];
+    if (mask_by_pos) {
+        if ((int)lane < D) mk = mask_tile[(size_t)(mask_by_pos - 1) + lane];
+    } else {
+        int ej = 0;
+#pragma unroll
+        for (int k = 0; k < D && k < VAR_INLINE; k++) asm("v_writelane_b32 %0, %1, %2" : "+v"(ej) : "s"(eid[k]), "n"(k));
+        if constexpr (D > VAR_INLINE)
+            if ((int)lane >= VAR_INLINE && (int)lane < D) ej = ce1[lane];
+        if ((int)lane < D) mk = mask_tile[ej];
+    }
     const int nlo = (int)(unsigned)mk.x, nhi = (int)(unsigned)(mk.x >> 32), alo = (int)(unsigned)mk.y, ahi = (int)(unsigned)(mk.y >> 32);
     float mm[D], pp[D], m2[D];
     u64 ag[D];
@@ -1467,7 +1478,7 @@ __global__ __launch_bounds__(256) void k_var_rec(const int *__restrict__ list, c
                                                  const float *__restrict__ prior, float *msg, const float *__restrict__ rec,
                                                  const ulonglong2 *__restrict__ mask, float *__restrict__ post,
                                                  u64 *__restrict__ hard, const u64 *__restrict__ done, int skip_done, int n, int m,
-                                                 long E, int write_out, int blk0)
+                                                 long E, int write_out, int blk0, int mask_by_pos)
 {
     const unsigned lane = threadIdx.x & 63u;
     const int tl = blockIdx.y;
@@ -1488,7 +1499,7 @@ __global__ __launch_bounds__(256) void k_var_rec(const int *__restrict__ list, c
     float L = pr;
 #define VR(D)                                                                                   \
     case D:                                                                                     \
-        if constexpr (D <= CAP) L = var_col_rec<D, SC1>(tb, rb, rb2, mt, lane, rc, w4, ce, cr, pr); \
+        if constexpr (D <= CAP) L = var_col_rec<D, SC1>(tb, rb, rb2, mt, lane, rc, w4, ce, cr, pr, mask_by_pos ? cb + 1 : 0); \
         break;
 #define VR8(D) VR(D) VR(D + 1) VR(D + 2) VR(D + 3) VR(D + 4) VR(D + 5) VR(D + 6) VR(D + 7)
     switch (d) {
