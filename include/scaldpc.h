@@ -212,6 +212,9 @@ int scaldpc_bp_last_stats(scaldpc_bp *h, int64_t *out);
  *   "rec_maskpos"   1 (default) = the record form's lane masks are laid out by POSITION in the variable pass's edge order
  *                   (a column's masks contiguous: its gather becomes one coalesced load; the check pass scatters its
  *                   16-B stores instead); 0 = by edge id (A/B).  (SCALDPC_REC_MASKPOS)
+ *   "rec_xmap"      1 (default) = the record form's variable pass maps workgroups to tiles by XCD (launches of 2, 4 or 8
+ *                   tiles): every XCD's L2 then holds the record planes of one tile of the launch; 0 = tile = blockIdx.y
+ *                   (A/B).  Placement is a speed matter only.  (SCALDPC_REC_XMAP)
  *   "rec_skip1"     1 (default) = in the record form a variable pass WITHOUT output (fixed-iteration runs, every pass but
  *                   the first and the last) leaves out the columns of degree <= 1: such a column always sends its prior,
  *                   iteration 1 has written it into the message array and the record check pass never overwrites it

@@ -79,6 +79,7 @@ struct Knobs {
     int var_form = 1;         // k_var: 0 = ids fetched edge by edge, 1 = all ids up front as wide scalar loads (default)
     int rec_sc1 = 1;          // record form: message stores of the variable pass leave the XCD's L2 (sc1); 0 = plain stores (A/B knob)
     int rec_maskpos = 1;      // record form: lane masks laid out by position in the re-laid edge list (a column's masks contiguous for the variable pass; scattered 16-B stores in the check pass); 0 = by edge id (A/B knob)
+    int rec_xmap = 1;         // record form: XCD-aware tile placement of the variable pass (every XCD's L2 sees the record planes of one of the launch's tiles); 0 = tile = blockIdx.y (A/B knob)
     int rec_skip1 = 1;        // record form: passes without output leave out the columns of degree <= 1 (their message is the prior, written once by iteration 1; the record check pass never overwrites it); 0 = all columns every pass (A/B knob)
     int minsum_rec = 1;       // min-sum on the tile kernels: check pass writes per-row records + lane masks instead of messages (k_check_minsum_rec / k_var_rec); 0 = message form
 };
@@ -241,6 +242,7 @@ bool set_knob(Knobs &k, const char *key, const char *val)
     else if (!strcmp(key, "minsum_rec")) k.minsum_rec = (int)x != 0;
     else if (!strcmp(key, "rec_sc1")) k.rec_sc1 = (int)x != 0;
     else if (!strcmp(key, "rec_skip1")) k.rec_skip1 = (int)x != 0;
+    else if (!strcmp(key, "rec_xmap")) k.rec_xmap = (int)x != 0;
     else if (!strcmp(key, "rec_maskpos")) k.rec_maskpos = (int)x != 0;
     else if (!strcmp(key, "fuse_test")) k.fuse_test = (int)x != 0;
     else return false;
@@ -252,7 +254,7 @@ void knobs_from_env(Knobs &k)
     static const char *const names[][2] = {{"SCALDPC_PATH", "path"}, {"SCALDPC_SPLIT", "split"},
                                            {"SCALDPC_GROUP_MB", "group_mb"}, {"SCALDPC_EL_MAX", "el_max"},
                                            {"SCALDPC_EL_FUSE", "el_fuse"}, {"SCALDPC_COMPACT_AFTER", "compact_after"},
-                                           {"SCALDPC_VAR_ORDER", "var_order"}, {"SCALDPC_VAR_FORM", "var_form"}, {"SCALDPC_SPECULATE", "speculate"}, {"SCALDPC_FUSE_FINALIZE", "fuse_finalize"}, {"SCALDPC_TEST_OVERLAP", "test_overlap"}, {"SCALDPC_FIRST_FUSED", "first_fused"}, {"SCALDPC_FUSE_TEST", "fuse_test"}, {"SCALDPC_MINSUM_REC", "minsum_rec"}, {"SCALDPC_REC_SC1", "rec_sc1"}, {"SCALDPC_REC_SKIP1", "rec_skip1"}, {"SCALDPC_REC_MASKPOS", "rec_maskpos"}};
+                                           {"SCALDPC_VAR_ORDER", "var_order"}, {"SCALDPC_VAR_FORM", "var_form"}, {"SCALDPC_SPECULATE", "speculate"}, {"SCALDPC_FUSE_FINALIZE", "fuse_finalize"}, {"SCALDPC_TEST_OVERLAP", "test_overlap"}, {"SCALDPC_FIRST_FUSED", "first_fused"}, {"SCALDPC_FUSE_TEST", "fuse_test"}, {"SCALDPC_MINSUM_REC", "minsum_rec"}, {"SCALDPC_REC_SC1", "rec_sc1"}, {"SCALDPC_REC_SKIP1", "rec_skip1"}, {"SCALDPC_REC_XMAP", "rec_xmap"}, {"SCALDPC_REC_MASKPOS", "rec_maskpos"}};
     for (auto &nm : names)
         if (const char *e = getenv(nm[0])) (void)set_knob(k, nm[1], e);
     if (getenv("SCALDPC_MINSUM_LOOP")) k.minsum_loop = 1;  // presence switches it on, as before
@@ -844,12 +846,14 @@ int launch_var(scaldpc_bp *h, int G, float *post_g, u64 *hard_g, const u64 *done
         const int nblk = h->var_bk.blk[h->var_bk.nb];
         const int n1 = (h->var_bk.nb > 0 && h->var_bk.maxd[0] == 1) ? h->var_bk.blk[1] : 0;
         const bool slim = light && !write_out && h->kn.rec_skip1 && n1 > 0 && n1 < nblk;
-        const dim3 gridr((unsigned)(slim ? nblk - n1 : nblk), G);
-        const int blk0 = slim && !h->var_reversed ? n1 : 0;
+        const int nb_launch = slim ? nblk - n1 : nblk;
+        const bool xm = h->kn.rec_xmap && (G == 2 || G == 4 || G == 8);
+        const dim3 gridr((unsigned)(xm ? (nb_launch + 7) / 8 * 8 : nb_launch), G);
+        const int blk0 = slim && !h->var_reversed ? n1 : 0, xmap = xm ? nb_launch : 0;
 #define VAR_REC_LAUNCH(CAP, S1)                                                                                     \
     hipLaunchKernelGGL((k_var_rec<CAP, S1>), gridr, dim3(256), 0, s, h->d_var_meta, h->d_var_rows, h->d_csc_list, h->d_csc_row, \
                        h->d_prior, msg0, h->d_rec + (size_t)tile0 * h->m * 2 * TW, h->d_mask + (size_t)tile0 * h->E, post_g,  \
-                       hard_g, done_g, skip_done, h->n, h->m, h->E, write_out, blk0, h->kn.rec_maskpos)
+                       hard_g, done_g, skip_done, h->n, h->m, h->E, write_out, blk0, h->kn.rec_maskpos, xmap)
         if (h->kn.rec_sc1) {
             if (h->max_col_deg <= 16) VAR_REC_LAUNCH(16, true); else VAR_REC_LAUNCH(32, true);
         } else {

@@ -1478,11 +1478,20 @@ __global__ __launch_bounds__(256) void k_var_rec(const int *__restrict__ list, c
                                                  const float *__restrict__ prior, float *msg, const float *__restrict__ rec,
                                                  const ulonglong2 *__restrict__ mask, float *__restrict__ post,
                                                  u64 *__restrict__ hard, const u64 *__restrict__ done, int skip_done, int n, int m,
-                                                 long E, int write_out, int blk0, int mask_by_pos)
+                                                 long E, int write_out, int blk0, int mask_by_pos, int xmap)
 {
     const unsigned lane = threadIdx.x & 63u;
-    const int tl = blockIdx.y;
-    const int ri = rfl(((int)blockIdx.x + blk0) * 4 + (int)(threadIdx.x >> 6));  // blk0: first block of the launch's slice of the records
+    int tl = blockIdx.y, bx = blockIdx.x;
+    if (xmap) {
+        // xmap = blocks per tile of this launch (G = 2, 4 or 8 tiles, grid.x a multiple of 8): workgroups are dealt
+        // round-robin over the 8 XCDs by linear index, so tile = (linear index % 8) % G gives every XCD's L2 the record
+        // planes of ONE of the launch's tiles instead of all of them.  Placement is a speed matter only.
+        const unsigned G = gridDim.y, L = blockIdx.y * gridDim.x + blockIdx.x, xcd = L & 7u, slot = L >> 3;
+        tl = (int)(xcd % G);
+        bx = (int)(slot * (8u / G) + xcd / G);
+        if (bx >= xmap) return;
+    }
+    const int ri = rfl((bx + blk0) * 4 + (int)(threadIdx.x >> 6));  // blk0: first block of the launch's slice of the records
     const int *rc = list + (size_t)ri * VAR_REC;
     const u64 dn = done[tl];
     if (skip_done && dn == ~0ull) return;

@@ -444,7 +444,8 @@ def test_minsum_record_form_is_invisible(oracle):
     the alpha = 1 - 2^-it schedule, early exit with the convergence test riding on the record check pass and without,
     the first iteration with and without its check pass, one and two stream lanes, compaction, plain and sc1 stores,
     fixed-iteration passes with and without the columns of degree <= 1 (`rec_skip1`: their message is the prior, written
-    once), lane masks laid out by position or by edge id (`rec_maskpos`), rows appended to a live decoder.  A graph with a row wider than 64 (or a column wider than 32) falls back to the
+    once), lane masks laid out by position or by edge id (`rec_maskpos`), XCD-aware tile placement on and off (`rec_xmap`: groups
+    of 2, 3 and 4 tiles), rows appended to a live decoder.  A graph with a row wider than 64 (or a column wider than 32) falls back to the
     message form by itself."""
     rng = np.random.RandomState(77)
     cases = []
@@ -466,12 +467,12 @@ def test_minsum_record_form_is_invisible(oracle):
     cases.append((G2, p2, s2, "syndrome", 0.75))
     for graph, pr, x, kind, alpha in cases:
         outs = {}
-        for form in ((1, 1), (1, 0), (0, 0)):  # (minsum_rec, rec_sc1 = rec_skip1 = rec_maskpos)
+        for form in ((1, 1), (1, 0), (0, 0)):  # (minsum_rec, rec_sc1 = rec_skip1 = rec_maskpos = rec_xmap)
             res = []
             for lanes, group, compact, ff, ft in ((2, 3, -1, 1, 1), (1, 2, 0, 0, 1), (2, 0, 2, 1, 0)):
                 with np.errstate(divide="ignore"):
                     dec = bp.bp_decoder(graph, max_iter=30, bp_method="min_sum", channel_probs=pr, ms_scaling_factor=alpha)
-                dec.configure(path="stream", minsum_rec=form[0], rec_sc1=form[1], rec_skip1=form[1], rec_maskpos=form[1], split=lanes, compact_after=compact,
+                dec.configure(path="stream", minsum_rec=form[0], rec_sc1=form[1], rec_skip1=form[1], rec_maskpos=form[1], rec_xmap=form[1], split=lanes, compact_after=compact,
                               first_fused=ff, fuse_test=ft)
                 dec.set_tile_group(group)
                 res.append(dec.decode_batch(x, early_exit=True, want_llr=True, input_vector_type=kind))
