@@ -606,9 +606,10 @@ int ensure_el_tables(scaldpc_bp *h)
 // exact-degree check kernels, the scalar-id variable kernel.
 bool rec_form(const scaldpc_bp *h, int method)
 {
+    // (columns of 33-64 edges: message form -- the exact-degree variable pass is compiled up to 32)
     return method == SCALDPC_BP_MIN_SUM && h->kn.minsum_rec && h->kn.minsum_loop == 0 && h->kn.var_form == 1 && h->E > 0 &&
-           h->max_row_deg <= 64 && h->max_col_deg <= 32 && !h->hg_var.has_generic;  // (columns of 33-64 edges: message form; the
-}                                                                                   //  exact-degree variable pass is compiled up to 32)
+           h->max_row_deg <= 64 && h->max_col_deg <= 32 && !h->hg_var.has_generic;
+}
 
 // message array of the tile path, G tiles (and the records of the min-sum record form)
 int ensure_msg(scaldpc_bp *h, int G, int method)
