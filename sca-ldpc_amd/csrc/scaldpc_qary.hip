@@ -54,6 +54,15 @@ __device__ __forceinline__ float vmin(float a, float b)
     return r;
 }
 
+// min of three in ONE instruction (v_min3_f32 = v_min_f32 of v_min_f32: a quiet NaN operand is ignored, as in vmin)
+__device__ __forceinline__ float vmin3(float a, float b, float c)
+{
+    float r;
+    asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+
+
 // decoder.rs:668-692 on the device: llr[q] = ln(max_p / p[q]) in f32, with glibc's logf restated
 // for the device (scaldpc_logf.h) and the correctly rounded f32 division, so the LLRs are bit for bit
 // what the reference's f32::ln gives on the host -- for host and device inputs alike.
@@ -357,14 +366,6 @@ struct QEnum {
         (QEnum<Q, K, J + 1, D..., Qs>::run(A, Bt, S + A[J][Qs], nconf), ...);
     }
 };
-// min of three in ONE instruction (v_min3_f32 = v_min_f32 of v_min_f32: a quiet NaN operand is ignored, as in vmin)
-__device__ __forceinline__ float vmin3(float a, float b, float c)
-{
-    float r;
-    asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
-    return r;
-}
-
 // Last FREE digit (edge K-2; edge K-1's digit then follows from sum d = 0): the up to Q assignments that differ only in
 // these two digits share the digit of every earlier edge j, i.e. they all lower the SAME beta[j][d_j].  Their candidates
 // S2_q - alpha[j][d_j] (each S2_q built left to right as before: the reference's additions in the reference's order) are
@@ -814,11 +815,26 @@ __global__ __launch_bounds__(64) void k_q_special_check_tree(const int *__restri
                 aw[u] = As[top - u];
                 mw[u] = ps0[-(ptrdiff_t)u * 64];
             }
+            // The d5 values of one d4 are taken two at a time: the minima they SHARE (the leading digits', d3's and d4's)
+            // take both candidates in one v_min3_f32 -- min is exact and order-free, the candidates are the same
+            // floats (each S built left to right as before) -- a seventh fewer VALU instructions in this loop.
 #pragma unroll
             for (int d4 = 0; d4 < QB; d4++) {
                 const float P4 = P3 + A4[d4];
 #pragma unroll
-                for (int d5 = 0; d5 < QB; d5++) {
+                for (int d5 = 0; d5 + 1 < QB; d5 += 2) {
+                    const float Sa = (P4 + A5[d5]) + aw[d4 + d5], Sb = (P4 + A5[d5 + 1]) + aw[d4 + d5 + 1];
+#pragma unroll
+                    for (int j = 0; j < NL; j++) ml[j] = vmin3(ml[j], Sa - al[j], Sb - al[j]);
+                    m3 = vmin3(m3, Sa - a3, Sb - a3);
+                    b4[d4] = vmin3(b4[d4], Sa - A4[d4], Sb - A4[d4]);
+                    b5[d5] = vmin(b5[d5], Sa - A5[d5]);
+                    b5[d5 + 1] = vmin(b5[d5 + 1], Sb - A5[d5 + 1]);
+                    mw[d4 + d5] = vmin(mw[d4 + d5], Sa - aw[d4 + d5]);
+                    mw[d4 + d5 + 1] = vmin(mw[d4 + d5 + 1], Sb - aw[d4 + d5 + 1]);
+                }
+                if constexpr (QB % 2 == 1) {
+                    constexpr int d5 = QB - 1;
                     const float S = (P4 + A5[d5]) + aw[d4 + d5];
 #pragma unroll
                     for (int j = 0; j < NL; j++) ml[j] = vmin(ml[j], S - al[j]);
