@@ -59,7 +59,7 @@ __global__ void k(const float *msg, const u64 *synd, float alpha, float *recA, f
     const int lane = threadIdx.x, r = blockIdx.x;
     const float *p = msg + (size_t)r * DEG * TW + lane;
     row_old<DEG, false>(p, synd[r], alpha, nullptr, nullptr, recA + r * TW, rec2A + r * TW, maskA + r * DEG, lane);
-    check_minsum_row_rec<DEG, false>(p, synd[r], alpha, nullptr, nullptr, recB + r * TW, rec2B + r * TW, maskB + r * DEG, lane);
+    check_minsum_row_rec<DEG, false>(p, synd[r], alpha, nullptr, nullptr, recB + r * TW, rec2B + r * TW, maskB + r * DEG, lane, nullptr);
 }
 template <int DEG>
 int run(int rows, unsigned seed)
