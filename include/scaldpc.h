@@ -156,8 +156,11 @@ int scaldpc_bp_decode_batch(scaldpc_bp *h, const uint8_t *in, int32_t input_kind
  *                   event (its duration = the distance to the previous event on its lane); because those events
  *                   cost the schedule its back-to-back dispatch, the same launch pattern is run once more WITHOUT
  *                   them, bracketed per lane, and ms[0] / ms[1] are scaled so that check + variable = the true pair
- *   launches[4]     codewords swept per variable launch;  launches[5] = 1 if min-sum ran in
- *                   its record form (k_check_minsum_rec / k_var_rec; knob "minsum_rec"), else 0
+ *   launches[4]     codewords swept per variable launch
+ *   launches[5]     bit 0: min-sum ran in its record form (k_check_minsum_rec / k_var_rec; knob "minsum_rec");
+ *                   bit 1: the variable pass was timed WITH its decision output -- the form every pass of an
+ *                   early-exit decode launches; the timing follows the last decode (fixed iterations: no output);
+ *                   bit 2: the timed variable launch left out the columns of degree <= 1 (record form, no output)
  */
 int scaldpc_bp_time_kernels(scaldpc_bp *h, int32_t iters, int32_t method, float alpha, void *stream,
                             float *ms, int32_t *launches);
@@ -181,53 +184,37 @@ int scaldpc_bp_last_compacted(scaldpc_bp *h, int64_t *count);
 int scaldpc_bp_last_stats(scaldpc_bp *h, int64_t *out);
 /* Tuning / test knobs of one handle.  A new handle takes its defaults from the environment ONCE, at
  * creation (SCALDPC_PATH, SCALDPC_SPLIT, SCALDPC_GROUP_MB, SCALDPC_EL_MAX, SCALDPC_EL_FUSE,
- * SCALDPC_COMPACT_AFTER, SCALDPC_MINSUM_LOOP, SCALDPC_VAR_ORDER, SCALDPC_VAR_FORM, SCALDPC_SPECULATE,
- * SCALDPC_FUSE_FINALIZE, SCALDPC_TEST_OVERLAP, SCALDPC_FIRST_FUSED, SCALDPC_FUSE_TEST); the
- * decode entry points never read
- * the environment.  key / value (text):
+ * SCALDPC_COMPACT_AFTER, SCALDPC_VAR_ORDER, SCALDPC_FIRST_FUSED, SCALDPC_FUSE_TEST, SCALDPC_MINSUM_REC,
+ * SCALDPC_REC_SKIP1); the decode entry points never read the environment.  Every knob selects a path, a size or a
+ * form that some graph or call still falls back to; the switches of variants that were measured and rejected
+ * (round 3's test_overlap, var_form, rec_maskpos, rec_xmap, rec_sc1, fuse_finalize, speculate, minsum_loop) are gone
+ * with their code (round 4; numbers in profiles/HISTORY.md) and are refused as unknown keys.  key / value (text):
  *   "path"          "auto" | "stream" (64-codeword tiles) | "edge" (row-parallel up to 64) | "lds"
  *   "split"         stream lanes per tile group (default 2)
  *   "group_mb"      budget of a cache-resident tile group in MB (default 215; large = stream from HBM)
  *   "el_max"        largest call the row-parallel kernels take (default 6 min-sum / 4 tanh)
  *   "el_fuse"       1 = two-launch early-exit loop of the row-parallel path (default), 0 = four-launch
  *   "compact_after" iteration from which stragglers may be handed to a compact pass (default 4, 0 = never)
- *   "minsum_loop"   1 = loop form of the min-sum check kernel (A/B)
  *   "var_order"     launch order of the columns in a variable-node pass: bit 0 = inside a degree by first
  *                   edge id (else by column id), bit 1 = heaviest columns first; -1 (default) = auto:
  *                   2 when a tile group runs as one stream lane, 1 otherwise
- *   "var_form"      variable-node kernel: 1 = a wave fetches all its edge ids up front as wide scalar loads
- *                   (default), 0 = one scalar load per edge
- *   "speculate"     1 (default) = an early-exit tile group stops at the hand-over point without polling the
- *                   device once two groups in a row handed a small remainder to the compact pass there,
- *                   0 = every group polls
- *   "fuse_finalize" 1 (default) = convergence test and latch of the tile early-exit loop in one launch,
- *                   0 = two launches.
  *   "fuse_test"     1 (default) = in the early-exit tile loop the convergence test of an iteration rides on the check
  *                   pass of the next one (except where the host polls or stops), with sharded accumulators;
- *                   0 = a stand-alone launch after every variable pass (SCALDPC_FUSE_TEST).
+ *                   0 = a stand-alone launch after every variable pass (what poll iterations use anyway).
  *   "minsum_rec"    1 (default) = min-sum on the 64-codeword-tile kernels in its RECORD form: the check pass writes, per
  *                   row and codeword, the two magnitudes a min-sum check sends (8 B) and, per edge and tile, two lane
  *                   masks (sign, arg-min: 0.25 B per codeword) instead of 4 B per edge and codeword; the variable pass
- *                   rebuilds every message from them, bit for bit.  0 = messages both ways.  (SCALDPC_MINSUM_REC)
- *   "rec_maskpos"   1 (default) = the record form's lane masks are laid out by POSITION in the variable pass's edge order
- *                   (a column's masks contiguous: its gather becomes one coalesced load; the check pass scatters its
- *                   16-B stores instead); 0 = by edge id (A/B).  (SCALDPC_REC_MASKPOS)
- *   "rec_xmap"      1 (default) = the record form's variable pass maps workgroups to tiles by XCD (launches of 2, 4 or 8
- *                   tiles): every XCD's L2 then holds the record planes of one tile of the launch; 0 = tile = blockIdx.y
- *                   (A/B).  Placement is a speed matter only.  (SCALDPC_REC_XMAP)
+ *                   rebuilds every message from them, bit for bit.  0 = messages both ways (what graphs with a row
+ *                   wider than 64 or a column wider than 32 use anyway).
  *   "rec_skip1"     1 (default) = in the record form a variable pass WITHOUT output (fixed-iteration runs, every pass but
  *                   the first and the last) leaves out the columns of degree <= 1: such a column always sends its prior,
  *                   iteration 1 has written it into the message array and the record check pass never overwrites it
- *                   (the identity block of an HQC graph: 4000 of 21669 column waves per tile).  0 = all columns (A/B).
- *   "rec_sc1"       1 (default) = the record form's variable pass stores its messages with sc1 (the line leaves the
- *                   XCD's L2, which keeps it for the row records); 0 = plain stores (A/B).  (SCALDPC_REC_SC1)
+ *                   (the identity block of an HQC graph: 4000 of 21669 column waves per tile).  0 = all columns (what
+ *                   passes with output launch anyway).
  *   "first_fused"   1 (default) = iteration 1 of the tile kernels runs without its check pass: the first variable
  *                   pass takes the first check-to-variable messages from a per-edge table (the message of a
- *                   zero-syndrome codeword) and the row's syndrome bit; 0 = check pass + plain variable pass
- *                   (SCALDPC_FIRST_FUSED).
- *   "test_overlap"  1 = that launch runs on a side stream of its lane, beside the check pass of the next iteration
- *                   (it feeds only the next VARIABLE pass), 0 (default) = in line (SCALDPC_TEST_OVERLAP; measured
- *                   3.4 % slower on the config-5 sweep, kept for the record).
+ *                   zero-syndrome codeword) and the row's syndrome bit; 0 = check pass (reading the priors) + plain
+ *                   variable pass, both in the message form (what graphs with a row or column wider than 64 use anyway).
  *   Results never depend on any of these. */
 int scaldpc_bp_configure(scaldpc_bp *h, const char *key, const char *value);
 /* Where a handle lives, out[4]: the device it was created on; the device (hipPointerGetAttributes)

@@ -239,7 +239,10 @@ class BpDecoder:
             )
         )
         return {"ms_check": ms[0], "ms_var": ms[1], "launches_check": ln[0], "launches_var": ln[1], "codewords": ln[2],
-                "lanes": ln[3], "codewords_var": ln[4], "record_form": bool(ln[5])}
+                "lanes": ln[3], "codewords_var": ln[4], "record_form": bool(ln[5] & 1),
+                # the variable pass is timed in the form the last decode launched it in (early exit: every pass writes
+                # decisions for all columns; fixed iterations: no output, record form without the degree <= 1 columns)
+                "var_writes_out": bool(ln[5] & 2), "var_slim": bool(ln[5] & 4)}
 
     # -- Monte-Carlo helpers on the device (K6) --------------------------------------
     def mc_fer_run(self, runs, seed, first_trial=0, max_iter=None, early_exit=True, want_errors=False):

@@ -59,8 +59,11 @@ struct HostBuckets {
 // handle
 // ===========================================================================
 // Tuning / test knobs of a handle.  The environment is read ONCE, when the handle is created
-// (SCALDPC_PATH, _SPLIT, _GROUP_MB, _EL_MAX, _EL_FUSE, _COMPACT_AFTER, _MINSUM_LOOP); afterwards
+// (SCALDPC_PATH, _SPLIT, _GROUP_MB, _EL_MAX, _EL_FUSE, _COMPACT_AFTER, ...); afterwards
 // scaldpc_bp_configure() changes them -- the decode entry points never call getenv().
+// Round 4 pruned the knobs that only switched a measured-and-rejected variant back on (test_overlap, var_form = 0,
+// rec_maskpos = 0, rec_xmap = 0, rec_sc1 = 0, fuse_finalize = 0, speculate = 0, minsum_loop; numbers in
+// profiles/HISTORY.md): what is left selects a path, a size, or a form that something still falls back to.
 struct Knobs {
     enum Path { AUTO = 0, STREAM = 1, EDGE = 2, LDS = 3 };
     int path = AUTO;
@@ -69,17 +72,9 @@ struct Knobs {
     int el_max = -1;          // row-parallel limit; -1 = per-method default (6 / 4)
     int el_fuse = 1;          // early-exit row-parallel loop: fused two-launch form
     int compact_after = -1;   // -1 = default (4); 0 = no compact pass
-    int minsum_loop = 0;      // loop form of the min-sum check kernel (A/B knob)
     int var_order = -1;       // k_var launch order: bit 0 = inside a degree by first edge id, bit 1 = heaviest columns first; -1 = auto
-    int fuse_finalize = 1;    // tile early-exit loop: convergence test and latch in one launch (k_parity_fin); 0 = k_parity + k_finalize
-    int speculate = 1;        // early-exit tile groups: stop at the hand-over point without polling once two groups in a row did (0 = always poll)
     int fuse_test = 1;        // early-exit tile loop: the convergence test of iteration it rides on the check pass of it + 1 wherever the host does not need the verdict in between
     int first_fused = 1;      // iteration 1 of the tile kernels without its check pass (k_var_first from the first-message table); 0 = check pass + plain variable pass
-    int test_overlap = 0;     // early-exit tile groups: 1 = the convergence test of iteration it runs on a side stream beside the check pass of it + 1 (A/B knob: measured 3.4 % SLOWER on the config-5 sweep, profiles/r03/ab_test_overlap.log)
-    int var_form = 1;         // k_var: 0 = ids fetched edge by edge, 1 = all ids up front as wide scalar loads (default)
-    int rec_sc1 = 1;          // record form: message stores of the variable pass leave the XCD's L2 (sc1); 0 = plain stores (A/B knob)
-    int rec_maskpos = 1;      // record form: lane masks laid out by position in the re-laid edge list (a column's masks contiguous for the variable pass; scattered 16-B stores in the check pass); 0 = by edge id (A/B knob)
-    int rec_xmap = 1;         // record form: XCD-aware tile placement of the variable pass (every XCD's L2 sees the record planes of one of the launch's tiles); 0 = tile = blockIdx.y (A/B knob)
     int rec_skip1 = 1;        // record form: passes without output leave out the columns of degree <= 1 (their message is the prior, written once by iteration 1; the record check pass never overwrites it); 0 = all columns every pass (A/B knob)
     int minsum_rec = 1;       // min-sum on the tile kernels: check pass writes per-row records + lane masks instead of messages (k_check_minsum_rec / k_var_rec); 0 = message form
 };
@@ -197,8 +192,6 @@ struct scaldpc_bp {
     int device = 0;  // the device the handle (and its stream) was created on
     hipStream_t aux_stream[4] = {};  // further lanes of a tile group (iterate_tiles)
     hipEvent_t ev_join[4] = {}, ev_phase[4] = {};
-    hipStream_t test_stream[4] = {};  // per lane: the side stream of the overlapped convergence test (iterate_tiles)
-    hipEvent_t ev_var[4] = {}, ev_test[4] = {};  // "variable pass of the lane enqueued" / "its convergence test enqueued"
     // Set by the first SCALDPC_F_ASYNC call and never cleared: work may be in flight when a later call
     // (or destroy) releases a buffer, so this handle's blocks go back through hipFree (which
     // waits for the device) instead of being parked for immediate reuse.
@@ -207,6 +200,7 @@ struct scaldpc_bp {
     // disagree, so every later call on the handle returns an error instead of decoding on it; destroy still frees all.
     bool broken = false;
     int last_group = 0;  // tiles of the last decoded group (for scaldpc_bp_time_kernels)
+    bool last_early = false;  // ... and whether that decode ran with early exit (its variable passes then all write decisions)
     std::mutex mu;
 };
 
@@ -232,18 +226,10 @@ bool set_knob(Knobs &k, const char *key, const char *val)
     else if (!strcmp(key, "el_max")) k.el_max = (int)x;
     else if (!strcmp(key, "el_fuse")) k.el_fuse = (int)x != 0;
     else if (!strcmp(key, "compact_after")) k.compact_after = (int)x;
-    else if (!strcmp(key, "minsum_loop")) k.minsum_loop = (int)x != 0;
     else if (!strcmp(key, "var_order")) k.var_order = (int)x;
-    else if (!strcmp(key, "var_form")) k.var_form = (int)x;
-    else if (!strcmp(key, "speculate")) k.speculate = (int)x != 0;
-    else if (!strcmp(key, "fuse_finalize")) k.fuse_finalize = (int)x != 0;
-    else if (!strcmp(key, "test_overlap")) k.test_overlap = (int)x != 0;
     else if (!strcmp(key, "first_fused")) k.first_fused = (int)x != 0;
     else if (!strcmp(key, "minsum_rec")) k.minsum_rec = (int)x != 0;
-    else if (!strcmp(key, "rec_sc1")) k.rec_sc1 = (int)x != 0;
     else if (!strcmp(key, "rec_skip1")) k.rec_skip1 = (int)x != 0;
-    else if (!strcmp(key, "rec_xmap")) k.rec_xmap = (int)x != 0;
-    else if (!strcmp(key, "rec_maskpos")) k.rec_maskpos = (int)x != 0;
     else if (!strcmp(key, "fuse_test")) k.fuse_test = (int)x != 0;
     else return false;
     return true;
@@ -254,10 +240,11 @@ void knobs_from_env(Knobs &k)
     static const char *const names[][2] = {{"SCALDPC_PATH", "path"}, {"SCALDPC_SPLIT", "split"},
                                            {"SCALDPC_GROUP_MB", "group_mb"}, {"SCALDPC_EL_MAX", "el_max"},
                                            {"SCALDPC_EL_FUSE", "el_fuse"}, {"SCALDPC_COMPACT_AFTER", "compact_after"},
-                                           {"SCALDPC_VAR_ORDER", "var_order"}, {"SCALDPC_VAR_FORM", "var_form"}, {"SCALDPC_SPECULATE", "speculate"}, {"SCALDPC_FUSE_FINALIZE", "fuse_finalize"}, {"SCALDPC_TEST_OVERLAP", "test_overlap"}, {"SCALDPC_FIRST_FUSED", "first_fused"}, {"SCALDPC_FUSE_TEST", "fuse_test"}, {"SCALDPC_MINSUM_REC", "minsum_rec"}, {"SCALDPC_REC_SC1", "rec_sc1"}, {"SCALDPC_REC_SKIP1", "rec_skip1"}, {"SCALDPC_REC_XMAP", "rec_xmap"}, {"SCALDPC_REC_MASKPOS", "rec_maskpos"}};
+                                           {"SCALDPC_VAR_ORDER", "var_order"}, {"SCALDPC_FIRST_FUSED", "first_fused"},
+                                           {"SCALDPC_FUSE_TEST", "fuse_test"}, {"SCALDPC_MINSUM_REC", "minsum_rec"},
+                                           {"SCALDPC_REC_SKIP1", "rec_skip1"}};
     for (auto &nm : names)
         if (const char *e = getenv(nm[0])) (void)set_knob(k, nm[1], e);
-    if (getenv("SCALDPC_MINSUM_LOOP")) k.minsum_loop = 1;  // presence switches it on, as before
 }
 
 // bucket b holds nodes with bounds[b-1] < deg <= bounds[b]; beyond the last bound -> generic (maxd 0)
@@ -607,8 +594,8 @@ int ensure_el_tables(scaldpc_bp *h)
 bool rec_form(const scaldpc_bp *h, int method)
 {
     // (columns of 33-64 edges: message form -- the exact-degree variable pass is compiled up to 32)
-    return method == SCALDPC_BP_MIN_SUM && h->kn.minsum_rec && h->kn.minsum_loop == 0 && h->kn.var_form == 1 && h->E > 0 &&
-           h->max_row_deg <= 64 && h->max_col_deg <= 32 && !h->hg_var.has_generic;
+    return method == SCALDPC_BP_MIN_SUM && h->kn.minsum_rec && h->E > 0 && h->max_row_deg <= 64 && h->max_col_deg <= 32 &&
+           !h->hg_var.has_generic;
 }
 
 // message array of the tile path, G tiles (and the records of the min-sum record form)
@@ -677,7 +664,7 @@ bool fused_init(const scaldpc_bp *h, int method)
 bool check_can_test(const scaldpc_bp *h, int method)
 {
     if (h->E == 0) return false;
-    if (method == SCALDPC_BP_MIN_SUM) return h->max_row_deg <= ROW_CAP && h->kn.minsum_loop == 0;
+    if (method == SCALDPC_BP_MIN_SUM) return h->max_row_deg <= ROW_CAP;
     return true;
 }
 
@@ -690,32 +677,33 @@ int launch_check(scaldpc_bp *h, int method, float alpha, int G, const u64 *synd_
     float *const scr0 = h->d_scratch ? h->d_scratch + (size_t)tile0 * h->E * TW : nullptr;
     if (method == SCALDPC_BP_MIN_SUM) {
         dim3 grid((h->m + 3) / 4, G);
-#define MS_LAUNCH(W, F)                                                                                              \
-    hipLaunchKernelGGL((k_check_minsum<W, F>), grid, dim3(256), 0, s, h->d_row_ptr, msg0, synd_g, done_g, skip_done, \
+#define MS_LAUNCH(F)                                                                                                 \
+    hipLaunchKernelGGL((k_check_minsum<F>), grid, dim3(256), 0, s, h->d_row_ptr, msg0, synd_g, done_g, skip_done, \
                        h->m, h->E, alpha, h->d_col_idx, h->d_prior)
-        const bool loop_form = h->kn.minsum_loop != 0;  // A/B knob
-        if (rec_form(h, method)) {
+        // (a first check pass -- iteration 1 with first_fused off -- reads the priors and writes MESSAGES: the message
+        // form's kernel, followed by the message form's variable pass; the records start with iteration 2)
+        if (rec_form(h, method) && !first) {
             dim3 gridx(h->row_bk.blk[h->row_bk.nb], G);
             float *const rec0 = h->d_rec + (size_t)tile0 * h->m * 2 * TW;
             ulonglong2 *const mask0 = h->d_mask + (size_t)tile0 * h->E;
-#define MSR_LAUNCH(CAP, F)                                                                                          \
-    hipLaunchKernelGGL((k_check_minsum_rec<CAP, F>), gridx, dim3(256), 0, s, h->d_row_list, msg0, synd_g, done_g, skip_done, \
-                       h->m, h->E, alpha, h->d_col_idx, h->d_prior, rec0, mask0, h->kn.rec_maskpos ? h->d_csr_pos : nullptr)
+#define MSR_LAUNCH(CAP)                                                                                             \
+    hipLaunchKernelGGL((k_check_minsum_rec<CAP>), gridx, dim3(256), 0, s, h->d_row_list, msg0, synd_g, done_g, skip_done, \
+                       h->m, h->E, alpha, h->d_col_idx, rec0, mask0, h->d_csr_pos)
 #define MSR_PAR(CAP)                                                                                                \
-    hipLaunchKernelGGL((k_check_minsum_rec<CAP, false, true>), gridx, dim3(256), 0, s, h->d_row_list, msg0, synd_g, done_g, \
-                       skip_done, h->m, h->E, alpha, h->d_col_idx, h->d_prior, rec0, mask0, h->kn.rec_maskpos ? h->d_csr_pos : nullptr, *ft)
-            if (ft && !first) {
+    hipLaunchKernelGGL((k_check_minsum_rec<CAP, true>), gridx, dim3(256), 0, s, h->d_row_list, msg0, synd_g, done_g, \
+                       skip_done, h->m, h->E, alpha, h->d_col_idx, rec0, mask0, h->d_csr_pos, *ft)
+            if (ft) {
                 if (h->max_row_deg <= 16) MSR_PAR(16); else if (h->max_row_deg <= 32) MSR_PAR(32); else MSR_PAR(64);
             } else if (h->max_row_deg <= 16) {
-                if (first) MSR_LAUNCH(16, true); else MSR_LAUNCH(16, false);
+                MSR_LAUNCH(16);
             } else if (h->max_row_deg <= 32) {
-                if (first) MSR_LAUNCH(32, true); else MSR_LAUNCH(32, false);
+                MSR_LAUNCH(32);
             } else {
-                if (first) MSR_LAUNCH(64, true); else MSR_LAUNCH(64, false);
+                MSR_LAUNCH(64);
             }
 #undef MSR_PAR
 #undef MSR_LAUNCH
-        } else if (h->max_row_deg <= ROW_CAP && !loop_form) {
+        } else if (h->max_row_deg <= ROW_CAP) {
             dim3 gridx(h->row_bk.blk[h->row_bk.nb], G);
 #define MSX_LAUNCH(CAP, F)                                                                                          \
     hipLaunchKernelGGL((k_check_minsum_x<CAP, F>), gridx, dim3(256), 0, s, h->d_row_list, msg0, synd_g, done_g, skip_done, \
@@ -734,10 +722,8 @@ int launch_check(scaldpc_bp *h, int method, float alpha, int G, const u64 *synd_
             }
 #undef MSX_PAR
 #undef MSX_LAUNCH
-        } else if (h->max_row_deg <= ROW_CAP) {
-            if (first) MS_LAUNCH(false, true); else MS_LAUNCH(false, false);
-        } else {
-            if (first) MS_LAUNCH(true, true); else MS_LAUNCH(true, false);
+        } else {  // a row wider than 64: the loop form
+            if (first) MS_LAUNCH(true); else MS_LAUNCH(false);
         }
 #undef MS_LAUNCH
     } else {
@@ -768,8 +754,8 @@ int launch_check(scaldpc_bp *h, int method, float alpha, int G, const u64 *synd_
 // kernel (rows of at most 64 edges), the first variable pass keeps every column in registers (columns of at most 64).
 bool first_fusable(const scaldpc_bp *h, int method)
 {
-    return h->kn.first_fused && h->kn.var_form == 1 && fused_init(h, method) && h->E > 0 && h->max_row_deg <= 64 &&
-           h->max_col_deg <= 64 && !h->hg_var.has_generic;
+    return h->kn.first_fused && fused_init(h, method) && h->E > 0 && h->max_row_deg <= 64 && h->max_col_deg <= 64 &&
+           !h->hg_var.has_generic;
 }
 
 // first_tab for (method, alpha of iteration 1) and the current priors: the row-parallel check kernel decodes the first
@@ -848,38 +834,28 @@ int launch_var(scaldpc_bp *h, int G, float *post_g, u64 *hard_g, const u64 *done
         const int n1 = (h->var_bk.nb > 0 && h->var_bk.maxd[0] == 1) ? h->var_bk.blk[1] : 0;
         const bool slim = light && !write_out && h->kn.rec_skip1 && n1 > 0 && n1 < nblk;
         const int nb_launch = slim ? nblk - n1 : nblk;
-        const bool xm = h->kn.rec_xmap && (G == 2 || G == 4 || G == 8);
+        // XCD-aware tile placement where the launch's tiles divide the 8 XCDs (fetch 38.0 -> 29.5 MB per launch, profiles/r03/ab_rec_xmap.log)
+        const bool xm = G == 2 || G == 4 || G == 8;
         const dim3 gridr((unsigned)(xm ? (nb_launch + 7) / 8 * 8 : nb_launch), G);
         const int blk0 = slim && !h->var_reversed ? n1 : 0, xmap = xm ? nb_launch : 0;
-#define VAR_REC_LAUNCH(CAP, S1)                                                                                     \
-    hipLaunchKernelGGL((k_var_rec<CAP, S1>), gridr, dim3(256), 0, s, h->d_var_meta, h->d_var_rows, h->d_csc_list, h->d_csc_row, \
+#define VAR_REC_LAUNCH(CAP)                                                                                         \
+    hipLaunchKernelGGL((k_var_rec<CAP>), gridr, dim3(256), 0, s, h->d_var_meta, h->d_var_rows, h->d_csc_list, h->d_csc_row, \
                        h->d_prior, msg0, h->d_rec + (size_t)tile0 * h->m * 2 * TW, h->d_mask + (size_t)tile0 * h->E, post_g,  \
-                       hard_g, done_g, skip_done, h->n, h->m, h->E, write_out, blk0, h->kn.rec_maskpos, xmap)
-        if (h->kn.rec_sc1) {
-            if (h->max_col_deg <= 16) VAR_REC_LAUNCH(16, true); else VAR_REC_LAUNCH(32, true);
-        } else {
-            if (h->max_col_deg <= 16) VAR_REC_LAUNCH(16, false); else VAR_REC_LAUNCH(32, false);
-        }
+                       hard_g, done_g, skip_done, h->n, h->m, h->E, write_out, blk0, xmap)
+        if (h->max_col_deg <= 16) VAR_REC_LAUNCH(16); else VAR_REC_LAUNCH(32);
 #undef VAR_REC_LAUNCH
         LAUNCH_CHECK();
         return 0;
     }
-#define VAR_LAUNCH(CAP, FORM)                                                                                       \
-    hipLaunchKernelGGL((k_var<CAP, FORM>), grid, dim3(256), 0, s, h->var_bk, h->d_var_meta, h->d_col_ptr, h->d_csc_list, \
+#define VAR_LAUNCH(CAP)                                                                                             \
+    hipLaunchKernelGGL((k_var<CAP>), grid, dim3(256), 0, s, h->var_bk, h->d_var_meta, h->d_col_ptr, h->d_csc_list, \
                        h->d_prior, msg0, scr0, post_g, hard_g, done_g, skip_done, h->n, h->E, write_out)
-    if (h->kn.var_form == 1) {  // A/B: edge ids fetched up front as wide scalar loads, SGPR-base gathers
-        if (h->max_col_deg <= 16)
-            VAR_LAUNCH(16, 1);
-        else if (h->max_col_deg <= 32)
-            VAR_LAUNCH(32, 1);
-        else
-            VAR_LAUNCH(64, 1);
-    } else if (h->max_col_deg <= 16)
-        VAR_LAUNCH(16, 0);
+    if (h->max_col_deg <= 16)
+        VAR_LAUNCH(16);
     else if (h->max_col_deg <= 32)
-        VAR_LAUNCH(32, 0);
+        VAR_LAUNCH(32);
     else
-        VAR_LAUNCH(64, 0);
+        VAR_LAUNCH(64);
 #undef VAR_LAUNCH
     LAUNCH_CHECK();
     return 0;
@@ -1021,17 +997,6 @@ int ensure_lanes(scaldpc_bp *h, int nl)
     if (nl > 1 && !h->ev_join[0]) SC_HIP(hipEventCreateWithFlags(&h->ev_join[0], hipEventDisableTiming));  // [0]: the fork event
     return 0;
 }
-int ensure_test_streams(scaldpc_bp *h, int nl)
-{
-    for (int k = 0; k < nl; k++)
-        if (!h->test_stream[k]) {
-            int dev = 0;
-            SC_TRY(stream_acquire(&h->test_stream[k], &dev));
-            SC_HIP(hipEventCreateWithFlags(&h->ev_var[k], hipEventDisableTiming));
-            SC_HIP(hipEventCreateWithFlags(&h->ev_test[k], hipEventDisableTiming));
-        }
-    return 0;
-}
 // What the groups of one call learn from each other about polling (a poll drains the queue: the GPU idles
 // while the host turns around, ~4 % of a group's time on the config-5 sweep):
 //   hint   poll points before this iteration saw no codeword finish in earlier groups: skip them
@@ -1075,28 +1040,7 @@ int iterate_tiles(scaldpc_bp *h, const TileState &st, int g0, int g, int max_ite
         SC_HIP(hipEventRecord(h->ev_join[0], s));
         for (int k = 1; k < nl; k++) SC_HIP(hipStreamWaitEvent(lane[k], h->ev_join[0], 0));
     }
-    // Early-exit runs: the convergence test of iteration it (k_parity_fin: reads the decisions the variable pass just
-    // wrote, latches done / conv / iters) does not feed the check pass of iteration it + 1 (messages only), so it runs on
-    // a side stream of its lane BESIDE that check pass; the lane waits for it before its next variable pass, the first
-    // reader of the `done` mask that matters.  (The check pass reads `done` only to skip a tile that is frozen as a
-    // whole: if it races with the latch that freezes the tile, some of its rows update messages nobody reads again.)
-    // The test is latency-bound (15 us per launch, 12 % of the GPU time of the config-5 sweep when serialised) and
-    // moves 2 % of a check pass's bytes -- and still the overlap does not pay: 366 k trials/s against 379 k in line
-    // (two runs each, identical results, profiles/r03/ab_test_overlap.log).  Two lanes already keep the fabric
-    // saturated, so the test's gathers are not free beside a check pass, and the two extra event hops per iteration
-    // and lane lengthen the dependency chain.  Kept as an A/B knob, OFF by default.
-    const bool ovl = early && h->kn.fuse_finalize && h->kn.test_overlap && h->E > 0;
-    if (ovl) SC_TRY(ensure_test_streams(h, nl));
-    bool test_pending[MAX_LANES] = {};
-    auto wait_test = [&](int k) -> int {  // lane k goes on only after its convergence test in flight
-        if (test_pending[k]) {
-            SC_HIP(hipStreamWaitEvent(lane[k], h->ev_test[k], 0));
-            test_pending[k] = false;
-        }
-        return 0;
-    };
     auto join = [&]() -> int {
-        for (int k = 0; k < nl; k++) SC_TRY(wait_test(k));
         for (int k = 1; k < nl; k++) {
             SC_HIP(hipEventRecord(h->ev_join[k], lane[k]));
             SC_HIP(hipStreamWaitEvent(s, h->ev_join[k], 0));
@@ -1108,7 +1052,9 @@ int iterate_tiles(scaldpc_bp *h, const TileState &st, int g0, int g, int max_ite
     if (first_fuse) SC_TRY(ensure_first_table(h, method, alpha_for(alpha, 1), s));
     // The convergence test of iteration it rides on the check pass of it + 1 (fused_test) wherever the host does not need
     // its verdict in between: at the iterations it polls at, stops a group at, or ends with, the stand-alone launch stays.
-    const bool ride = early && h->kn.fuse_finalize && h->kn.fuse_test && !ovl && check_can_test(h, method) && pw >= FT_WORDS;
+    // (Running the test on a side stream beside the check pass instead was measured and rejected: -3.4 % on the config-5
+    // sweep, profiles/r03/ab_test_overlap.log; so was the two-launch k_parity + k_finalize form in this loop.)
+    const bool ride = early && h->kn.fuse_test && check_can_test(h, method) && pw >= FT_WORDS;
     bool verdict_pending[MAX_LANES] = {};  // lane k's last variable pass has not been tested yet: its next check pass will
     bool set_phase = true;  // (re-)establish the one-kernel offset between neighbouring lanes
     for (int it = 1; it <= max_iter; it++) {
@@ -1134,19 +1080,14 @@ int iterate_tiles(scaldpc_bp *h, const TileState &st, int g0, int g, int max_ite
         if (!no_check) set_phase = false;  // (a first iteration without check passes leaves the offset to the second)
         for (int k = 0; k < nl; k++) {
             const int ta = g0 + t0[k];
-            SC_TRY(wait_test(k));  // the test of the previous iteration decides which codewords this pass may still write
+            // (the record form starts with iteration 2: an iteration 1 that has a check pass ran it in the message form)
             SC_TRY(launch_var(h, gs[k], st.post ? st.post + (size_t)ta * h->n * TW : nullptr, st.hard + (size_t)ta * h->n,
                               st.done + ta, skip, (early || last) ? 1 : 0, lane[k], t0[k],
-                              no_check ? st.synd + (size_t)ta * h->m : nullptr, !no_check && rec_form(h, method), it > 1));
+                              no_check ? st.synd + (size_t)ta * h->m : nullptr, it > 1 && rec_form(h, method), it > 1));
             if (ride && !last && !poll) {
                 verdict_pending[k] = true;  // the next check pass of this lane carries the test
-            } else if ((early || last) && h->kn.fuse_finalize) {  // convergence test + latch, one launch
+            } else if (early || last) {  // convergence test + latch, one launch
                 hipStream_t ts = lane[k];
-                if (ovl) {
-                    ts = h->test_stream[k];
-                    SC_HIP(hipEventRecord(h->ev_var[k], lane[k]));
-                    SC_HIP(hipStreamWaitEvent(ts, h->ev_var[k], 0));
-                }
                 if (pw >= FT_WORDS && h->kn.fuse_test) {  // sharded accumulators / counters (fused_commit)
                     const FusedTest pf{st.hard + (size_t)ta * h->n, st.unsat + (size_t)ta * pw, st.done + ta, st.conv + ta,
                                        st.iters + (size_t)ta * TW, rem + it, h->n, pw, it, early ? 1 : 0};
@@ -1158,25 +1099,12 @@ int iterate_tiles(scaldpc_bp *h, const TileState &st, int g0, int g, int max_ite
                                        st.synd + (size_t)ta * h->m, st.unsat + (size_t)ta * pw, pw, it, early ? 1 : 0, st.done + ta,
                                        st.conv + ta, st.iters + (size_t)ta * TW, rem + it);
                 LAUNCH_CHECK();
-                if (ovl) {
-                    SC_HIP(hipEventRecord(h->ev_test[k], ts));
-                    test_pending[k] = true;
-                }
-            } else if (early || last) {
-                hipLaunchKernelGGL(k_parity<true>, dim3((h->m + 4 * ROWS_PER_WAVE - 1) / (4 * ROWS_PER_WAVE), gs[k]), dim3(256),
-                                   0, lane[k], h->d_row_ptr, h->d_col_idx, st.hard + (size_t)ta * h->n, h->m, h->n,
-                                   const_cast<u64 *>(st.synd + (size_t)ta * h->m), st.unsat + (size_t)ta * pw,
-                                   (const u64 *)(st.done + ta));
-                LAUNCH_CHECK();
-                hipLaunchKernelGGL(k_finalize, dim3(gs[k]), dim3(64), 0, lane[k], it, early ? 1 : 0, st.done + ta, st.conv + ta,
-                                   st.unsat + (size_t)ta * pw, pw, st.iters + (size_t)ta * TW, rem + it);
-                LAUNCH_CHECK();
             }
         }
         // a poll drains the queue (the GPU idles while the host turns around): skip the poll
         // points at which the call's earlier groups saw no codeword finish yet (`poll`, above)
         if (early && !last && poll && ps && it == defer_after && defer_after > 0 && 2 * it < max_iter && ps->streak >= 2 &&
-            ps->since_poll < 15 && h->kn.speculate) {
+            ps->since_poll < 15) {
             ps->since_poll++;  // stop here unseen, as the last groups did
             *deferred = true;
             return join();
@@ -1271,7 +1199,10 @@ int decode_level(scaldpc_bp *h, int lvl, const TileState &st, int batch, int T, 
         SC_TRY(ensure_el(h, el));
     else
         SC_TRY(ensure_msg(h, Gl, method));
-    if (lvl == 0) h->last_group = el ? 0 : Gl;
+    if (lvl == 0) {
+        h->last_group = el ? 0 : Gl;
+        h->last_early = early;
+    }
     if (el) h->stat_el = el;
     h->stat_levels = lvl;
 
@@ -1281,7 +1212,7 @@ int decode_level(scaldpc_bp *h, int lvl, const TileState &st, int batch, int T, 
         if (h->kn.compact_after >= 0) defer_after = h->kn.compact_after;
         if (max_iter <= 2 * defer_after) defer_after = 0;  // nothing to gain
     }
-    if (!el && h->kn.fuse_finalize)  // accumulators and block counters of the convergence tests: zero once, every launch leaves them zero
+    if (!el)  // accumulators and block counters of the convergence tests: zero once, every launch leaves them zero
         SC_HIP(hipMemsetAsync(st.unsat, 0, sizeof(u64) * (size_t)T * parity_waves(h), s));
     std::vector<char> deferred_tile(T, 0);
     bool any = false;
@@ -2302,6 +2233,13 @@ int scaldpc_bp_time_kernels(scaldpc_bp *h, int32_t iters, int32_t method, float 
     const int g = h->last_group;
     SC_TRY(ensure_msg(h, g, method));  // (a method other than the last decode's may want the record arrays)
     const int nl = std::min(fixed_lanes(h, g), 2);
+    // The variable pass is timed in the form the last decode launched it in: early-exit runs write decisions on EVERY
+    // pass (all columns), fixed-iteration runs only on the last one (the passes before it leave out the columns of
+    // degree <= 1 in the record form).  launches[5] says which.
+    const int wo = h->last_early ? 1 : 0;
+    const bool recf = rec_form(h, method);
+    const bool slim = recf && !wo && h->kn.rec_skip1;
+    const int form_bits = (recf ? 1 : 0) | (wo ? 2 : 0) | (slim ? 4 : 0);
     // `iters` back-to-back launches of each kernel between two events: the event
     // overhead (a few us, comparable to a 65 us launch) is amortised, what remains is
     // the kernel plus the ~1.5 us dependent-launch gap it also pays in a real decode.
@@ -2319,7 +2257,7 @@ int scaldpc_bp_time_kernels(scaldpc_bp *h, int32_t iters, int32_t method, float 
         for (int it = 0; it < iters && !rc; it++) rc = launch_check(h, method, alpha_for(alpha, it + 1), g, h->d_synd, h->d_done, 0, s);
         SC_HIP(hipEventRecord(ev[1], s));
         SC_HIP(hipEventRecord(ev[2], s));
-        for (int it = 0; it < iters && !rc; it++) rc = launch_var(h, g, nullptr, h->d_hard, h->d_done, 0, 0, s, 0, nullptr, rec_form(h, method), true);
+        for (int it = 0; it < iters && !rc; it++) rc = launch_var(h, g, nullptr, h->d_hard, h->d_done, 0, wo, s, 0, nullptr, recf, true);
         SC_HIP(hipEventRecord(ev[3], s));
         if (!rc) SC_HIP(hipStreamSynchronize(s));
         if (!rc) {
@@ -2328,7 +2266,7 @@ int scaldpc_bp_time_kernels(scaldpc_bp *h, int32_t iters, int32_t method, float 
             launches[0] = launches[1] = iters;
             launches[2] = launches[4] = g * TW;  // codewords swept per launch
             launches[3] = 1;
-            launches[5] = rec_form(h, method) ? 1 : 0;
+            launches[5] = form_bits;
         }
     } else {
         SC_TRY(ensure_lanes(h, 2));
@@ -2352,8 +2290,8 @@ int scaldpc_bp_time_kernels(scaldpc_bp *h, int32_t iters, int32_t method, float 
                 }
             }
             for (int k = 0; k < 2 && !rc; k++) {
-                rc = launch_var(h, gs[k], nullptr, h->d_hard + (size_t)t0[k] * h->n, h->d_done + t0[k], 0, 0, lane[k], t0[k], nullptr,
-                                rec_form(h, method), true);
+                rc = launch_var(h, gs[k], nullptr, h->d_hard + (size_t)t0[k] * h->n, h->d_done + t0[k], 0, wo, lane[k], t0[k], nullptr,
+                                recf, true);
                 SC_HIP(hipEventRecord(M(k, 2 * it + 2), lane[k]));
             }
         }
@@ -2396,8 +2334,8 @@ int scaldpc_bp_time_kernels(scaldpc_bp *h, int32_t iters, int32_t method, float 
                         }
                     }
                     for (int k = 0; k < 2 && !rc; k++)
-                        rc = launch_var(h, gs[k], nullptr, h->d_hard + (size_t)t0[k] * h->n, h->d_done + t0[k], 0, 0, lane[k], t0[k],
-                                        nullptr, rec_form(h, method), true);
+                        rc = launch_var(h, gs[k], nullptr, h->d_hard + (size_t)t0[k] * h->n, h->d_done + t0[k], 0, wo, lane[k], t0[k],
+                                        nullptr, recf, true);
                 }
                 SC_HIP(hipEventRecord(e0, lane[0]));
                 SC_HIP(hipEventRecord(e1, lane[1]));
@@ -2423,7 +2361,7 @@ int scaldpc_bp_time_kernels(scaldpc_bp *h, int32_t iters, int32_t method, float 
             launches[2] = gs[0] * TW;
             launches[4] = gs[0] * TW;  // (odd groups: the second lane's launches are one tile smaller)
             launches[3] = 2;
-            launches[5] = rec_form(h, method) ? 1 : 0;
+            launches[5] = form_bits;
         }
         for (auto &e : mark) (void)hipEventDestroy(e);
     }
@@ -2466,9 +2404,6 @@ void scaldpc_bp_destroy(scaldpc_bp *h)
         if (h->aux_stream[k]) stream_release(h->aux_stream[k], h->device);
         if (h->ev_join[k]) (void)hipEventDestroy(h->ev_join[k]);
         if (h->ev_phase[k]) (void)hipEventDestroy(h->ev_phase[k]);
-        if (h->test_stream[k]) stream_release(h->test_stream[k], h->device);
-        if (h->ev_var[k]) (void)hipEventDestroy(h->ev_var[k]);
-        if (h->ev_test[k]) (void)hipEventDestroy(h->ev_test[k]);
     }
     delete h;
 }

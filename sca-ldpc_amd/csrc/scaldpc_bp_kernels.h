@@ -3,11 +3,26 @@
 // translation unit; the split is for reading, not for linking.
 #pragma once
 
+// v_writelane_b32 as an instruction the COMPILER emits: ROCm 7.2's clang has no __builtin_amdgcn_writelane, but the LLVM
+// intrinsic is reachable through an asm label.  Unlike an `asm("v_writelane_b32 ...")` statement the hazard recogniser
+// sees its SGPR operand, so the 2 wait states gfx950 needs between a VALU write of an SGPR (v_cmp, v_readlane -- e.g. a
+// spill reload the register allocator put there) and this VALU read of it are padded (profiles/isa_lint.py
+// checks the built code object).
+extern "C" __device__ int scaldpc_llvm_writelane(int src, int lane, int old) __asm("llvm.amdgcn.writelane.i32");
+
 namespace {
+
+__device__ __forceinline__ unsigned writelane(unsigned src, int lane, unsigned old)
+{
+    return (unsigned)scaldpc_llvm_writelane((int)src, lane, (int)old);
+}
 
 constexpr int TW = 64;       // codewords per tile = one wavefront of lanes
 constexpr int MAXB = 8;      // degree buckets per node kind
 constexpr int ROW_CAP = 64;  // largest register-resident row degree (also the sign-mask width)
+#ifndef REC_CHUNK
+#define REC_CHUNK 8
+#endif
 
 __device__ __forceinline__ int rfl(int x) { return __builtin_amdgcn_readfirstlane(x); }
 
@@ -501,14 +516,15 @@ __global__ __launch_bounds__(256) void k_init_msg(const int *__restrict__ col_id
 //   c2v_k = alpha * (-1)^(s + #{k' != k : v2c_k' <= 0}) * min_{k' != k} |v2c_k'|
 // The reference package obtains the exclusive minimum by a forward and a backward
 // running min; min is exact, so (min1, min2, first argmin) gives the identical
-// value with ONE pass over the inputs.  Signs of all inputs are kept in a 64-bit
-// mask per codeword (rows of degree <= 64); WIDE rows re-read the input instead
-// (reading edge k before overwriting edge k keeps that legal in place).
+// value with ONE pass over the inputs.  This LOOP form serves graphs with a row wider
+// than 64 (the register-resident forms below take everything else): the second sweep
+// re-reads the inputs for their signs (reading edge k before overwriting edge k keeps
+// that legal in place).
 // wave = (row, tile), lane = codeword.  grid (ceil(m/4), G), block 256 = 4 rows.
 // ---------------------------------------------------------------------------
 // FIRST: iteration 1 takes its inputs straight from the priors (v2c = prior of the edge's
 // column by definition), so the message array needs no initialisation pass and is not read.
-template <bool WIDE, bool FIRST>
+template <bool FIRST>
 __global__ __launch_bounds__(256) void k_check_minsum(const int *__restrict__ row_ptr, float *msg,
                                                       const u64 *__restrict__ synd, const u64 *__restrict__ done,
                                                       int skip_done, int m, long E, float alpha,
@@ -525,14 +541,12 @@ __global__ __launch_bounds__(256) void k_check_minsum(const int *__restrict__ ro
     unsigned par = (unsigned)(synd[(size_t)tl * m + r] >> lane) & 1u;
     float m1 = FLT_MAX, m2 = FLT_MAX;
     int ix = 0;
-    u64 neg = 0;
 #pragma unroll 16
     for (int k = 0; k < deg; k++) {
         const float x = FIRST ? prior[rfl(col_idx[e0 + k])] : p[(size_t)k * TW];
         const float a = fabsf(x);
         const unsigned n_ = x <= 0.0f;
         par ^= n_;
-        if (!WIDE) neg |= (u64)n_ << k;
         const bool lt = a < m1;
         m2 = lt ? m1 : ((a < m2) ? a : m2);
         ix = lt ? k : ix;
@@ -541,8 +555,7 @@ __global__ __launch_bounds__(256) void k_check_minsum(const int *__restrict__ ro
     const float nalpha = -alpha;
 #pragma unroll 8
     for (int k = 0; k < deg; k++) {
-        const unsigned b = WIDE ? (unsigned)((FIRST ? prior[rfl(col_idx[e0 + k])] : p[(size_t)k * TW]) <= 0.0f)
-                                : ((unsigned)(neg >> k) & 1u);
+        const unsigned b = (unsigned)((FIRST ? prior[rfl(col_idx[e0 + k])] : p[(size_t)k * TW]) <= 0.0f);
         p[(size_t)k * TW] = ((k == ix) ? m2 : m1) * ((par ^ b) ? nalpha : alpha);
     }
 }
@@ -649,19 +662,18 @@ __global__ __launch_bounds__(256) void k_check_minsum_x(const int *__restrict__ 
 //            edge that attains m1, as `ix` was: arg = eq & ~found, found |= eq (scalar); sign = negative ^ parity
 //            (scalar); the two masks go into lane k of the output registers with v_writelane.
 // 10 VALU instructions per edge.
-template <int DEG, bool FIRST>
-__device__ __forceinline__ void check_minsum_row_rec(const float *p, u64 synd_mask, float alpha, const float *__restrict__ prior,
-                                                     const int *__restrict__ cidx, float *__restrict__ rec,
+template <int DEG>
+__device__ __forceinline__ void check_minsum_row_rec(const float *p, u64 synd_mask, float alpha, float *__restrict__ rec,
                                                      float *__restrict__ rec2, ulonglong2 *__restrict__ mask, int lane,
                                                      const int *__restrict__ pos)
 {
-    // pos != nullptr: the masks are laid out in the variable pass's order (position of the edge in the re-laid edge list:
-    // a column's masks are contiguous there); lane k fetches edge k's position up front
-    int mp = lane;
-    if (pos && lane < DEG) mp = pos[lane];
+    // the masks are laid out in the variable pass's order (position of the edge in the re-laid edge list: a column's
+    // masks are contiguous there); lane k fetches edge k's position up front
+    int mp = 0;
+    if (lane < DEG) mp = pos[lane];
     float x[DEG];
 #pragma unroll
-    for (int k = 0; k < DEG; k++) x[k] = FIRST ? prior[rfl(cidx[k])] : p[(size_t)k * TW];
+    for (int k = 0; k < DEG; k++) x[k] = p[(size_t)k * TW];
     float m1 = FLT_MAX, m2 = FLT_MAX;
     const float fmax = FLT_MAX;
     u64 par = ((u64)(unsigned)rfl((int)(synd_mask >> 32)) << 32) | (unsigned)rfl((int)synd_mask);  // (uniform by construction: keep it on the scalar side)
@@ -676,32 +688,42 @@ __device__ __forceinline__ void check_minsum_row_rec(const float *p, u64 synd_ma
     rec[lane] = m1 * alpha;
     rec2[lane] = m2 * alpha;
     unsigned nlo = 0, nhi = 0, alo = 0, ahi = 0;  // lane k keeps edge k's two masks
-    // `found` starts as a zero the compiler cannot see through: every mask that reaches a v_writelane below is then the
-    // result of a SCALAR instruction (s_xor / s_andn2).  A v_writelane in inline asm that reads an SGPR the v_cmp right
-    // in front of it has just written gets the OLD value on gfx950 (the compiler's hazard recogniser pads its own
-    // instructions, not the inside of an asm statement): measured with edge 0's arg-min mask of degree-1 rows
-    // (profiles/microbench/rec_row_equivalence.hip).
-    u64 found;
-    asm volatile("s_mov_b64 %0, 0" : "=s"(found));
+    // The v_writelanes below are the compiler's own instructions (writelane(), top of this file): a v_writelane reading an
+    // SGPR that a VALU instruction -- a v_cmp, or a v_readlane reloading a spilled mask -- wrote fewer than 2 wait states
+    // earlier gets the OLD value on gfx950, and inside an `asm` statement nobody pads (round 3 measured it on edge 0's
+    // arg-min mask of degree-1 rows; its work-around, masks routed through a scalar instruction, could not reach the
+    // register allocator's spill reloads: VERDICT r03 #1).
+    u64 found = 0;
 #pragma unroll
     for (int k = 0; k < DEG; k++) {
+        // the sweep runs in chunks of REC_CHUNK edges: a chunk's compares wait (through an empty asm on their inputs) for
+        // the previous chunk's v_writelanes, so at most a chunk's masks are live in SGPRs.  Left alone the scheduler
+        // hoists the ballots of the whole row (and keeps sweep 1's sign masks for reuse): 128+ live SGPR pairs, 684 static
+        // SGPR spills in the 64-edge build, every one a v_writelane / v_readlane pair on the VALU this kernel is bound by.
+        if (k % REC_CHUNK == 0) {
+            asm volatile("" ::"v"(nlo), "v"(nhi), "v"(alo), "v"(ahi));
+#pragma unroll
+            for (int j = k; j < DEG && j < k + REC_CHUNK; j++) asm volatile("" : "+v"(x[j]));
+        }
         const u64 ng = __ballot(x[k] <= 0.0f) ^ par;
         const u64 eq = __ballot(fabsf(x[k]) == m1);
         const u64 ag = eq & ~found;
         found |= eq;
-        asm("v_writelane_b32 %0, %1, %2" : "+v"(nlo) : "s"((unsigned)ng), "n"(k));
-        asm("v_writelane_b32 %0, %1, %2" : "+v"(nhi) : "s"((unsigned)(ng >> 32)), "n"(k));
-        asm("v_writelane_b32 %0, %1, %2" : "+v"(alo) : "s"((unsigned)ag), "n"(k));
-        asm("v_writelane_b32 %0, %1, %2" : "+v"(ahi) : "s"((unsigned)(ag >> 32)), "n"(k));
+        nlo = writelane((unsigned)ng, k, nlo);
+        nhi = writelane((unsigned)(ng >> 32), k, nhi);
+        alo = writelane((unsigned)ag, k, alo);
+        ahi = writelane((unsigned)(ag >> 32), k, ahi);
     }
     if (lane < DEG) mask[mp] = make_ulonglong2(((u64)nhi << 32) | nlo, ((u64)ahi << 32) | alo);
 }
 
-template <int CAP, bool FIRST, bool PAR = false>
+// (Iteration 1 never comes here: it runs without a check pass -- k_var_first -- or, with first_fused off, in the message
+// form, whose check kernel reads the priors.)
+template <int CAP, bool PAR = false>
 __global__ __launch_bounds__(256) void k_check_minsum_rec(const int *__restrict__ list, const float *msg,
                                                           const u64 *__restrict__ synd, const u64 *done,
                                                           int skip_done, int m, long E, float alpha,
-                                                          const int *__restrict__ col_idx, const float *__restrict__ prior,
+                                                          const int *__restrict__ col_idx,
                                                           float *__restrict__ rec, ulonglong2 *__restrict__ mask,
                                                           const int *__restrict__ csr_pos, FusedTest ft = FusedTest{})
 {
@@ -724,12 +746,12 @@ __global__ __launch_bounds__(256) void k_check_minsum_rec(const int *__restrict_
         const int deg = md[2];
         const float *p = msg + ((size_t)tl * E + e0) * TW + lane;
         float *rc = rec + ((size_t)tl * 2 * m + r) * TW, *rc2 = rc + (size_t)m * TW;  // two planes per tile: [m1 | m2][row][64]
-        ulonglong2 *mk = mask + (size_t)tl * E + (csr_pos ? 0 : e0);  // (by position: the tile's base; by edge: the row's first)
-        const int *ps = csr_pos ? csr_pos + e0 : nullptr;
+        ulonglong2 *mk = mask + (size_t)tl * E;  // (masks by position: the tile's base)
+        const int *ps = csr_pos + e0;
         const u64 sw = synd[(size_t)tl * m + r];  // (uniform: a scalar load; the row's syndrome bits ARE a lane mask)
 #define MR(D)                                                                                                       \
     case D:                                                                                                         \
-        if constexpr (D <= CAP) check_minsum_row_rec<D, FIRST>(p, sw, alpha, prior, col_idx + e0, rc, rc2, mk, lane, ps); \
+        if constexpr (D <= CAP) check_minsum_row_rec<D>(p, sw, alpha, rc, rc2, mk, lane, ps); \
         break;
 #define MR8(D) MR(D) MR(D + 1) MR(D + 2) MR(D + 3) MR(D + 4) MR(D + 5) MR(D + 6) MR(D + 7)
         switch (deg) {
@@ -1075,37 +1097,11 @@ __global__ __launch_bounds__(256) void k_bp_small(const int *__restrict__ row_pt
 // edge list in the re-laid list, degree, unroll bound, first VAR_INLINE edge ids}.
 constexpr int VAR_INLINE = 16, VAR_REC = 4 + VAR_INLINE;
 
-// ce0: the record's inline edge ids (k < VAR_INLINE), ce1: the column's full list (k beyond)
-template <int MAXD>
-__device__ __forceinline__ float var_col(float *mt, const int *__restrict__ ce0, const int *__restrict__ ce1, int d,
-                                         float pr)
-{
-    float mm[MAXD], pp[MAXD];
-#pragma unroll
-    for (int k = 0; k < MAXD; k++)
-        if (k < d) mm[k] = mt[(size_t)rfl(k < VAR_INLINE ? ce0[k] : ce1[k]) * TW];
-    float temp = pr;
-#pragma unroll
-    for (int k = 0; k < MAXD; k++)
-        if (k < d) {
-            pp[k] = temp;
-            temp += mm[k];
-        }
-    float suf = 0.0f;
-#pragma unroll
-    for (int k = MAXD - 1; k >= 0; k--)
-        if (k < d) {
-            mt[(size_t)rfl(k < VAR_INLINE ? ce0[k] : ce1[k]) * TW] = pp[k] + suf;
-            suf += mm[k];
-        }
-    return temp;
-}
-
-// Same column update with the edge ids fetched FIRST, all of them, as wide scalar loads (the record's
-// inline ids, then the column's list), so that the gathers issue back to back: in the form above the
-// compiler fetches one id per edge with `s_load_dword` + `s_waitcnt lgkmcnt(0)` right in front of each
+// The column update with the edge ids fetched FIRST, all of them, as wide scalar loads (the record's
+// inline ids, then the column's list), so that the gathers issue back to back: with one id fetched per
+// edge the compiler puts an `s_load_dword` + `s_waitcnt lgkmcnt(0)` right in front of each
 // gather (the branch on `k < d` keeps it from hoisting them), i.e. the gathers of a degree-11 column
-// leave the wave a scalar-cache round trip apart.  The message row of edge e is addressed as
+// leave the wave a scalar-cache round trip apart (round 2: 65.0 -> 63.5 us, profiles/r02/ab_*.json).  The message row of edge e is addressed as
 // (uniform base + e * 256) + lane * 4: the edge enters on the scalar side (SGPR base of the
 // global_load), the lane offset is the one VGPR.  Same operations, same order: identical results.
 template <int MAXD>
@@ -1248,7 +1244,7 @@ __device__ __forceinline__ float var_col_generic(float *mt, float *st, const int
 // write_out: also emit hard-decision planes (merged under the done mask) and, if
 // `post` is non-null, the posterior of every not-yet-frozen codeword.
 // CAP = largest unroll bound compiled in (see k_check_tanh).
-template <int CAP, int FORM = 0>
+template <int CAP>
 __global__ __launch_bounds__(256) void k_var(Buckets bk, const int *__restrict__ list,
                                              const int *__restrict__ col_ptr, const int *__restrict__ csc_edge,
                                              const float *__restrict__ prior, float *msg, float *scratch,
@@ -1270,10 +1266,10 @@ __global__ __launch_bounds__(256) void k_var(Buckets bk, const int *__restrict__
     const int cb = rec[1];
     const int d = rec[2];
     float *mt = msg + (size_t)tl * E * TW + lane;
-    const int *ce = csc_edge + cb, *ce0 = rec + 4;
+    const int *ce = csc_edge + cb;
     const float pr = prior[v];
     float L = pr;
-    if constexpr (FORM == 1) {
+    {
         float *tb = msg + (size_t)tl * E * TW;
         const unsigned ul = threadIdx.x & 63u;  // unsigned lane index: lets the gathers take the SGPR-base form
         const int4 *r4 = (const int4 *)rec;
@@ -1291,20 +1287,6 @@ __global__ __launch_bounds__(256) void k_var(Buckets bk, const int *__restrict__
                 break;
             default: L = var_col_generic(mt, scratch + (size_t)tl * E * TW + lane, ce, d, pr);
         }
-    } else
-    switch (rec[3]) {
-        case 1: L = var_col<1>(mt, ce0, ce, d, pr); break;
-        case 2: L = var_col<2>(mt, ce0, ce, d, pr); break;
-        case 4: L = var_col<4>(mt, ce0, ce, d, pr); break;
-        case 8: L = var_col<8>(mt, ce0, ce, d, pr); break;
-        case 16: L = var_col<16>(mt, ce0, ce, d, pr); break;
-        case 32:
-            if constexpr (CAP >= 32) L = var_col<32>(mt, ce0, ce, d, pr);
-            break;
-        case 64:
-            if constexpr (CAP >= 64) L = var_col<64>(mt, ce0, ce, d, pr);
-            break;
-        default: L = var_col_generic(mt, scratch + (size_t)tl * E * TW + lane, ce, d, pr);
     }
     if (write_out) {
         const u64 hb = __ballot(L <= 0.0f);
@@ -1396,11 +1378,11 @@ __global__ __launch_bounds__(256) void k_var_first(const int *__restrict__ list,
 // for the column's EXACT degree, dispatched wave-uniformly: the bucketed form (unrolled to the bucket's bound,
 // predicated on `k < d`) spent more instructions on the predicates than on the column.
 //   csc_row: row of every position of the re-laid edge list (laid out like it), for edges beyond VAR_INLINE
-template <int D, bool SC1>
+template <int D>
 __device__ __forceinline__ float var_col_rec(float *tile_base, const float *__restrict__ rec_base,
-                                             const float *__restrict__ rec2_base, const ulonglong2 *__restrict__ mask_tile,
+                                             const float *__restrict__ rec2_base, const ulonglong2 *__restrict__ mask_col,
                                              unsigned lane, const int *__restrict__ rc, const int4 *__restrict__ row4,
-                                             const int *__restrict__ ce1, const int *__restrict__ cr1, float pr, int mask_by_pos)
+                                             const int *__restrict__ ce1, const int *__restrict__ cr1, float pr)
 {
     int eid[D], rid[D];
     {
@@ -1420,19 +1402,9 @@ __device__ __forceinline__ float var_col_rec(float *tile_base, const float *__re
             rid[k] = cr1[k];
         }
     }
-    // lane j's two masks: by position (mask_by_pos = the column's first position + 1: contiguous, no edge id needed) or by
-    // edge id (put into the lane with v_writelane)
+    // lane j's two masks (mask_col = the masks of the column's first position: a column's masks are contiguous)
     ulonglong2 mk = make_ulonglong2(0, 0);
-    if (mask_by_pos) {
-        if ((int)lane < D) mk = mask_tile[(size_t)(mask_by_pos - 1) + lane];
-    } else {
-        int ej = 0;
-#pragma unroll
-        for (int k = 0; k < D && k < VAR_INLINE; k++) asm("v_writelane_b32 %0, %1, %2" : "+v"(ej) : "s"(eid[k]), "n"(k));
-        if constexpr (D > VAR_INLINE)
-            if ((int)lane >= VAR_INLINE && (int)lane < D) ej = ce1[lane];
-        if ((int)lane < D) mk = mask_tile[ej];
-    }
+    if ((int)lane < D) mk = mask_col[lane];
     const int nlo = (int)(unsigned)mk.x, nhi = (int)(unsigned)(mk.x >> 32), alo = (int)(unsigned)mk.y, ahi = (int)(unsigned)(mk.y >> 32);
     float mm[D], pp[D], m2[D];
     u64 ag[D];
@@ -1460,25 +1432,22 @@ __device__ __forceinline__ float var_col_rec(float *tile_base, const float *__re
 #pragma unroll
     for (int k = D - 1; k >= 0; k--) {
         gfloat *q = sbase(tile_base + (size_t)rfl(eid[k]) * TW) + lane;
-        if constexpr (SC1)
-            __hip_atomic_store(q, pp[k] + suf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // sc1: the line does not stay in this XCD's L2
-        else
-            *q = pp[k] + suf;
+        // sc1: the line does not stay in this XCD's L2 (it is read next by a check pass on whichever XCD), which keeps
+        // the L2 for the records: 76.2 -> 74.3 ms per step on the HQC-128 bench (profiles/r03/ab_rec_l2.log)
+        __hip_atomic_store(q, pp[k] + suf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         suf += mm[k];
     }
     return temp;
 }
 
 // grid (bk.blk[nb], G), block 256 = 4 column records (k_var's launch shape and records).
-// SC1: the message stores leave this XCD's L2 (they are read next by a check pass on whichever XCD), which keeps the
-// L2 for the records: 76.2 -> 74.3 ms per step on the HQC-128 bench (profiles/r03/ab_rec_l2.log).
-template <int CAP, bool SC1 = false>
+template <int CAP>
 __global__ __launch_bounds__(256) void k_var_rec(const int *__restrict__ list, const int *__restrict__ var_rows,
                                                  const int *__restrict__ csc_edge, const int *__restrict__ csc_row,
                                                  const float *__restrict__ prior, float *msg, const float *__restrict__ rec,
                                                  const ulonglong2 *__restrict__ mask, float *__restrict__ post,
                                                  u64 *__restrict__ hard, const u64 *__restrict__ done, int skip_done, int n, int m,
-                                                 long E, int write_out, int blk0, int mask_by_pos, int xmap)
+                                                 long E, int write_out, int blk0, int xmap)
 {
     const unsigned lane = threadIdx.x & 63u;
     int tl = blockIdx.y, bx = blockIdx.x;
@@ -1508,7 +1477,7 @@ __global__ __launch_bounds__(256) void k_var_rec(const int *__restrict__ list, c
     float L = pr;
 #define VR(D)                                                                                   \
     case D:                                                                                     \
-        if constexpr (D <= CAP) L = var_col_rec<D, SC1>(tb, rb, rb2, mt, lane, rc, w4, ce, cr, pr, mask_by_pos ? cb + 1 : 0); \
+        if constexpr (D <= CAP) L = var_col_rec<D>(tb, rb, rb2, mt + cb, lane, rc, w4, ce, cr, pr); \
         break;
 #define VR8(D) VR(D) VR(D + 1) VR(D + 2) VR(D + 3) VR(D + 4) VR(D + 5) VR(D + 6) VR(D + 7)
     switch (d) {

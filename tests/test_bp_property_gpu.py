@@ -112,13 +112,12 @@ def test_random_instances(oracle, m, n, density, batch, method, received, early,
     method=st.sampled_from(["min_sum", "product_sum"]), early=st.booleans(),
     path=st.sampled_from(["auto", "stream", "edge"]), max_iter=st.integers(2, 40), seed=st.integers(0, 10_000),
     lanes=st.integers(1, 3), group=st.integers(0, 3), compact_after=st.sampled_from([None, 0, 2, 4]),
-    var_order=st.sampled_from([-1, 0, 1, 2, 3]), var_form=st.integers(0, 1), speculate=st.integers(0, 1),
-    fuse_finalize=st.integers(0, 1), test_overlap=st.integers(0, 1), first_fused=st.integers(0, 1), fuse_test=st.integers(0, 1),
-    minsum_rec=st.integers(0, 1), rec_sc1=st.integers(0, 1), rec_skip1=st.integers(0, 1), rec_maskpos=st.integers(0, 1), rec_xmap=st.integers(0, 1),
+    var_order=st.sampled_from([-1, 0, 1, 2, 3]), first_fused=st.integers(0, 1), fuse_test=st.integers(0, 1),
+    minsum_rec=st.integers(0, 1), rec_skip1=st.integers(0, 1),
 )
 def test_random_hqc_shaped_instances(oracle, N, W, rfrac, omega, eps, batch, method, early, path, max_iter, seed, lanes,
-                                     group, compact_after, var_order, var_form, speculate, fuse_finalize, test_overlap, first_fused, fuse_test,
-                                     minsum_rec, rec_sc1, rec_skip1, rec_maskpos, rec_xmap):
+                                     group, compact_after, var_order, first_fused, fuse_test,
+                                     minsum_rec, rec_skip1):
     """HQC-shaped graphs [Hin | I] too large for LDS (the tile kernels, the row-parallel kernels, the
     compaction levels and the stream lanes all come into play): random size, row weight, check count,
     noise (incl. certainty-1.0 checks), batch, iteration budget, scheduling knobs.  Bit-exact for
@@ -144,9 +143,8 @@ def test_random_hqc_shaped_instances(oracle, N, W, rfrac, omega, eps, batch, met
         with np.errstate(divide="ignore"):
             dec = bp.bp_decoder(H, max_iter=max_iter, bp_method=method, channel_probs=probs)
             dec.set_tile_group(group)
-            dec.configure(var_order=var_order, var_form=var_form, speculate=speculate, fuse_finalize=fuse_finalize,
-                          test_overlap=test_overlap, first_fused=first_fused, fuse_test=fuse_test, minsum_rec=minsum_rec,
-                          rec_sc1=rec_sc1, rec_skip1=rec_skip1, rec_maskpos=rec_maskpos, rec_xmap=rec_xmap)  # all invisible
+            dec.configure(var_order=var_order, first_fused=first_fused, fuse_test=fuse_test, minsum_rec=minsum_rec,
+                          rec_skip1=rec_skip1)  # all invisible
             got = dec.decode_batch(msg, early_exit=early, want_llr=True)
             dec.close()
             ref = oracle.bp_decode_batch(H, probs, msg, 1, max_iter, ORACLE_METHOD[method], dtype="f32", threads=8,
