@@ -437,7 +437,9 @@ def test_staircase_graph_every_degree(oracle, colmax, decode_path):
     assert cdeg.max() == colmax and set(Hd.sum(axis=1)) == set(range(1, 65)) and set(range(colmax + 1)) <= set(cdeg)
     probs = rng.uniform(0.01, 0.2, size=G.n)
     batch = 150  # three tiles, the last one ragged
-    err = (rng.rand(batch, G.n) < probs[None, :]).astype(np.uint8)
+    # error weights from none to the priors' own: codewords that stop at iteration 1, 2, 3 ... and some that never do
+    scale = np.array([0.0, 0.01, 0.03, 0.1, 0.3, 1.0])[np.arange(batch) % 6]
+    err = (rng.rand(batch, G.n) < probs[None, :] * scale[:, None]).astype(np.uint8)
     synd = G.syndrome(err)
     for method, max_iter in (("min_sum", 12), ("product_sum", 8)):
         refs = {early: oracle.bp_decode_batch(G, probs, synd, 0, max_iter, ORACLE_METHOD[method], dtype="f32", threads=8,
