@@ -10,14 +10,15 @@
             of the success flags after the timed region  -> "scaling": "weak"
 
 Also reported on the same JSON line:
-  roofline      dominant kernel = the one with the larger share of GPU time (k_var, the variable-node
-                update, on every HQC workload; the check-node kernel is a close second), algorithmic
-                bytes per launch (8 B per edge per codeword of the cache-resident tile group it
-                sweeps) / HIP-event launch duration vs the 8 TB/s HBM peak; `hbm_frac` = the same
-                kernels streaming from HBM (tile group far beyond the Infinity Cache) / that peak.
-                Min-sum runs in a RECORD form by default (k_check_minsum_rec / k_var_rec) that
-                moves about half the bytes: `frac` keeps the survey's algorithmic figure (16 B per edge-iteration, as
-                SURVEY 8d prescribes) and can exceed 1; `roofline.moved` = the PMC bytes of the launch pair / its time
+  roofline      `achieved` / `frac` = bytes REALLY MOVED (rocprofv3 FETCH_SIZE + WRITE_SIZE, taken live by two short child
+                runs) by a (check + variable) launch pair, all stream lanes, / the pair's HIP-event time, against the
+                8 TB/s HBM peak; `kernel` = the one with the larger share of the pair's time; `hbm_frac` = the same in
+                the HBM-streaming regime (one tile group = the whole batch); `cache_ceiling_GBps` = the measured ceiling
+                of the cache-resident regime (in-place stream of the tile group's size, scaldpc_measure_rmw_stream);
+                `algorithmic_*` = SURVEY 8d's figure (16 B per edge-iteration) over the same time -- for min-sum in its
+                RECORD form (k_check_minsum_rec / k_var_rec) about 1.6x what is moved, hence not a
+                fraction of anything; `updates_elided_frac` = the share of `value`'s updates served without computing a
+                message (iteration 1's table, degree-1 columns).  No field labelled `frac` exceeds 1 (self_check).
   cpu_baseline  the CPU oracle's f32 restatement (oracle/, a "port": the reference's own
                 decoder binaries cannot run here) on a bounded sample, host cores stated
 """
@@ -82,6 +83,8 @@ def main():
                     "rocprofv3 --pmc child runs (FETCH_SIZE, WRITE_SIZE) of this very workload before the timed run "
                     "(N=1 only; falls back to 'file'), 'file' = the committed profiles/*_pmc_traffic_*.json, 'off' = null")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)  # the short run the PMC passes profile
+    ap.add_argument("--pmc-save", default=None, help="write the live PMC bytes per kernel to this file (profiles/r04/"
+                    "pmc_traffic_<workload>.json is what a later run without counters falls back to)")
     ap.add_argument("--no-hbm-streaming", action="store_true", help="skip the extra pass with tile groups far beyond "
                     "the Infinity Cache (roofline.hbm_streaming_GBps)")
     ap.add_argument("--rendezvous-only", action="store_true", help="launch, rendezvous, one all_gather of the rank "
@@ -94,6 +97,13 @@ def main():
     live_traffic = None
     if args.gpus == 1 and args.pmc == "live" and not args.pmc_child and WORKLOADS[args.workload][0] and args.workload != "hqc128_mc":
         live_traffic = pmc_live(args.workload)
+        if live_traffic and args.pmc_save:
+            with open(args.pmc_save, "w") as fh:
+                json.dump(live_traffic, fh, indent=1)
+
+    args.sq_live = None
+    if (args.gpus == 1 and args.pmc == "live" and not args.pmc_child and args.workload in ("qary_config4", "kyber_sw6")):
+        args.sq_live = sq_live(args.workload, {"qary_config4": 1024, "kyber_sw6": 256}[args.workload] if args.batch == 4096 else args.batch)
 
     import torch
     import torch.distributed as dist
@@ -241,6 +251,7 @@ def main():
         check_gbs = 8.0 * E * swept / (ms_check * 1e-3) / 1e9  # 4 B read + 4 B written per edge per codeword
         var_gbs = 8.0 * E * kt["codewords_var"] / (ms_var_pass * 1e-3) / 1e9
         rec = bool(kt.get("record_form"))  # min-sum in its record form (knob minsum_rec): other kernels, same algorithmic bytes
+        kt_first_fused = os.environ.get("SCALDPC_FIRST_FUSED", "1") != "0"  # (HQC graphs: every row and column is register-resident)
         cname = ("k_check_minsum_rec" if rec else "k_check_minsum_x") if method == "min_sum" else "k_check_tanh"
         vname = "k_var_rec" if rec else "k_var"
         cpmc = ("k_check_minsum_rec" if rec else "k_check_minsum") if method == "min_sum" else "k_check_tanh"
@@ -275,84 +286,138 @@ def main():
         if per_rank_ms:
             out["per_rank_ms_per_step"] = per_rank_ms
             out["rank_ms_min_max"] = [min(per_rank_ms), max(per_rank_ms)]
-        # The kernel with the larger share of GPU time is the dominant one (k_var on every workload so
-        # far).  Under the two-lane schedule no kernel runs alone: each stream alternates check and
-        # variable launches over its half of the tile group, one kernel out of phase with the other
-        # stream, so `achieved` is the CHIP's algorithmic rate over a (check + variable) launch pair:
-        # lanes x (bytes of a check launch + bytes of a variable launch) / (t_check + t_var)
-        # (DESIGN.md section 5).  `per_launch` = each kernel's in-situ launch duration (what rocprofv3
-        # reports for it), `dominant` = the larger one, `isolated` = the same kernels alone on the chip.
-        # The messages of a tile group are served by the 256 MiB Infinity Cache by design (the group is
-        # sized for it), which is why `achieved` can exceed what HBM streaming sustains
-        # (`hbm_copy_ceiling_GBps`, `hbm_streaming_GBps`); `peak` stays the HBM datasheet figure the
-        # contract names.
+        # ---- roofline: what the hardware did --------------------------------------------------------------------------
+        # Under the two-lane schedule no kernel runs alone: each stream alternates check and variable launches over its
+        # half of the tile group, one kernel out of phase with the other stream.  The unit of account is therefore the
+        # (check + variable) launch PAIR of one lane; `lanes` of them run side by side.
+        #   achieved / frac   bytes REALLY MOVED over a pair (rocprofv3 FETCH_SIZE + WRITE_SIZE of both kernels, gfx950
+        #                     corrections applied) x lanes / the pair's HIP-event time, against the 8 TB/s HBM datasheet
+        #                     peak.  These are L2 <-> fabric bytes; a cache-resident tile group is served by the 256 MiB
+        #                     Infinity Cache, which is why the figure can sit above what HBM streaming sustains
+        #                     (hbm_copy_ceiling_GBps) -- `cache_ceiling_GBps` is the measured ceiling of that regime.
+        #   algorithmic_*     SURVEY 8(d)'s figure (two fp32 message arrays: 16 B per edge, codeword and iteration) over
+        #                     the same time.  Not a hardware rate: the record form of min-sum moves about half of it.
         dom_is_var = ms_var_pass >= ms_check
         dname = vname if dom_is_var else cname
-        achieved = lanes * (8.0 * E * swept + 8.0 * E * kt["codewords_var"]) / ((ms_check + ms_var_pass) * 1e-3) / 1e9
-        traffic, traffic_src = None, None
-        if live_traffic and live_traffic.get("codewords_per_launch") == swept:
-            tk = live_traffic["kernels"].get(vname if dom_is_var else cpmc)
-            if tk:
-                traffic, traffic_src = tk["traffic_bytes"], "live rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this run"
-        if traffic is None and args.pmc != "off":
-            traffic = pmc_traffic(args.workload, batch, swept, vname if dom_is_var else cpmc)
-            traffic_src = "profiles/ (committed PMC passes of this geometry)" if traffic is not None else None
+        pair_s = (ms_check + ms_var_pass) * 1e-3
+        algorithmic = lanes * (8.0 * E * swept + 8.0 * E * kt["codewords_var"]) / pair_s / 1e9
+        tr = live_traffic if (live_traffic and live_traffic.get("codewords_per_launch") == swept) else None
+        if tr is None and args.pmc != "off":
+            tr = pmc_traffic(args.workload, swept)
+        tc = tr["kernels"].get(cpmc) if tr else None
+        tv = tr["kernels"].get(vname) if tr else None
+        n1 = int((H.col_degrees() == 1).sum())  # edges into columns of degree 1 (the identity block of an HQC graph)
+        if tc and tv:
+            bytes_check, bytes_var, bytes_src = tc["traffic_bytes"], tv["traffic_bytes"], tr["source"]
+        else:  # no counters: the design's byte model, per launch
+            if rec:
+                bytes_check = swept * (4.0 * E + 8.0 * R + E / 4.0)
+                bytes_var = kt["codewords_var"] * (4.0 * (E - (n1 if kt.get("var_slim") else 0)) + E / 4.0 + 8.0 * R)
+            else:
+                bytes_check, bytes_var = 8.0 * E * swept, 8.0 * E * kt["codewords_var"]
+            bytes_src = "byte MODEL of DESIGN.md section 4 (no PMC counters available in this run, none committed for this geometry)"
+        moved = lanes * (bytes_check + bytes_var) / pair_s / 1e9
+        # iteration 1 and the elided updates, stated: with first_fused the first check pass is a table (no message is
+        # computed per codeword), and in the record form's passes without output the columns of degree <= 1 are not rewritten
+        elided = (E if kt_first_fused else 0) + (n1 * max(0, iters - 2) if (rec and kt.get("var_slim")) else 0)
         out["roofline"] = {
-            "bound": "infinity-cache",  # what serves the bytes; the contract's class for this path is "hbm" (no MFMA)
-            "bound_class": "hbm",
+            "bound": "hbm",
+            "served_by": "infinity-cache (a tile group's message array is sized to stay resident: 4 tiles = 209 MB on this graph); "
+                         "the bytes counted are L2 <-> fabric bytes, which HBM would carry if the cache did not",
             "kernel": dname,
-            "achieved": achieved,
+            "achieved": moved,
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
-            "frac": achieved / HBM_PEAK_GBS,
-            "traffic": traffic,
-            "traffic_source": traffic_src,
+            "frac": moved / HBM_PEAK_GBS,
+            "achieved_is": "bytes really moved by a (check + variable) launch pair (FETCH_SIZE + WRITE_SIZE of both kernels) x lanes "
+                           "/ the pair's HIP-event time",
+            "traffic": bytes_var if dom_is_var else bytes_check,
+            "traffic_source": bytes_src,
+            "pair": {"lanes": lanes, "us": pair_s * 1e6, "bytes_per_pair_and_lane": bytes_check + bytes_var,
+                     "bytes": {cname: bytes_check, vname: bytes_var}},
+            "algorithmic_GBps": algorithmic,
+            "algorithmic_frac": algorithmic / HBM_PEAK_GBS,
             "algorithmic_bytes_per_launch": 8.0 * E * (kt["codewords_var"] if dom_is_var else swept),
+            "scheme": "algorithmic_* = SURVEY 8(d): 8 B per directed edge-message update (one fp32 read + one written), 16 E per "
+                      "codeword and iteration, over the same pair time.  " + (
+                          "Min-sum runs in its RECORD form: the check pass reads 4E and writes two magnitudes per row + two lane masks "
+                          "per edge (8m + E/4), the variable pass writes 4E and reads E/4 of masks + the row records: about 8.7E per "
+                          "codeword and iteration through the fabric instead of 16E, so the algorithmic figure exceeds the hardware's "
+                          "rate and is NOT a roofline fraction" if rec else
+                          "Message form: both passes read and write every message, moved bytes = algorithmic bytes + index / prior / "
+                          "plane traffic"),
             "lanes": lanes,
+            "timed_variable_pass": {"writes_output": bool(kt.get("var_writes_out")), "without_degree_le1_columns": bool(kt.get("var_slim"))},
             "dominant": {"name": dname, "us": (ms_var_pass if dom_is_var else ms_check) * 1e3,
-                         "share_of_pair_time": max(ms_var_pass, ms_check) / (ms_check + ms_var_pass),
-                         "algorithmic_GBps": var_gbs if dom_is_var else check_gbs,
-                         # alone on the chip (one lane: its own rate; two lanes: filled in from `isolated` below)
-                         "frac": (var_gbs if dom_is_var else check_gbs) / HBM_PEAK_GBS if lanes == 1 else None},
+                         "share_of_pair_time": max(ms_var_pass, ms_check) / (ms_check + ms_var_pass)},
             "per_launch": {
-                cname: {"codewords": swept, "us": ms_check * 1e3, "algorithmic_GBps": check_gbs},
-                vname: {"codewords": kt["codewords_var"], "us": ms_var_pass * 1e3, "algorithmic_GBps": var_gbs},
+                cname: {"codewords": swept, "us": ms_check * 1e3, "moved_bytes": bytes_check, "algorithmic_GBps": check_gbs},
+                vname: {"codewords": kt["codewords_var"], "us": ms_var_pass * 1e3, "moved_bytes": bytes_var, "algorithmic_GBps": var_gbs},
             },
-            "hbm_streaming_GBps": hbm_stream["GBps"] if hbm_stream else None,
-            "hbm_streaming": hbm_stream,
-            # `frac` prices the ALGORITHMIC byte rate of the cache-resident schedule against the HBM datasheet peak (the
-            # contract's definition); the bytes are served by the Infinity Cache, so it is not an HBM utilisation.  The
-            # HBM-only figure: the same kernels with tile groups far beyond the cache / the same peak.
-            "frac_is": "algorithmic bytes of the cache-resident schedule / HBM datasheet peak (served by the Infinity Cache)",
-            "hbm_frac": hbm_stream["GBps"] / HBM_PEAK_GBS if hbm_stream else None,
+            "updates_elided_frac": elided / (2.0 * E * iters),
+            "updates_elided_what": "`value` counts 2 E updates per codeword and iteration; of those, iteration 1's check-to-variable "
+                                   "messages come from a per-edge table (first_fused) and, in fixed-iteration record-form runs, the "
+                                   "messages out of columns of degree <= 1 (always the prior) are written once instead of every pass: "
+                                   "identical results, fewer message updates actually performed",
         }
-        if rec:
-            out["roofline"]["scheme"] = (
-                "min-sum record form: `achieved` / `frac` keep SURVEY 8(d)'s ALGORITHMIC figure (two fp32 message arrays, 16 B per "
-                "edge, codeword and iteration), as the survey prescribes for an implementation that moves fewer real bytes; what the "
-                "kernels really move per codeword and iteration is 4E read + 8m + E/4 written (check) and 4E written + E/4 + the "
-                "row records (8m, re-read from L2 for every edge) read (variable): about 8.7E through the fabric")
-        if live_traffic:
-            out["roofline"]["traffic_all_kernels"] = live_traffic["kernels"]
-            tc, tv = live_traffic["kernels"].get(cpmc), live_traffic["kernels"].get(vname)
-            if tc and tv and live_traffic.get("codewords_per_launch") == swept:
-                # what the fabric really carried over a launch pair (PMC bytes of both kernels, every lane), beside the
-                # algorithmic figure `achieved` is defined on
-                moved = lanes * (tc["traffic_bytes"] + tv["traffic_bytes"]) / ((ms_check + ms_var_pass) * 1e-3) / 1e9
-                out["roofline"]["moved"] = {"GBps": moved, "frac_of_peak": moved / HBM_PEAK_GBS,
-                                            "bytes_per_pair_and_lane": tc["traffic_bytes"] + tv["traffic_bytes"],
-                                            "what": "FETCH_SIZE + WRITE_SIZE of the check and the variable launch, all lanes, over the pair's time"}
+        # whole step in moved bytes: (iters - 1) pairs per codeword group + the first variable pass, over ms_per_step
+        per_cw_pair = (bytes_check / max(1, swept) + bytes_var / max(1, kt["codewords_var"]))
+        first_cw = None
+        if tr and tr["kernels"].get("k_var_first"):
+            first_cw = tr["kernels"]["k_var_first"]["traffic_bytes"] / max(1, swept)
+        step_bytes = batch * ((iters - 1) * per_cw_pair + (first_cw if first_cw is not None else per_cw_pair))
+        out["roofline"]["whole_step"] = {"moved_GBps": step_bytes / (dt / args.steps) / 1e9,
+                                         "frac": step_bytes / (dt / args.steps) / 1e9 / HBM_PEAK_GBS,
+                                         "what": "PMC bytes per codeword of every launch of a step (first variable pass + iters - 1 pairs) "
+                                                 "x batch / ms_per_step: the driver-timed figure, launch gaps and I/O kernels included"}
+        if hbm_stream:
+            # the same kernels with ONE tile group = the whole batch, far beyond the cache: bytes per codeword-iteration
+            # from the counters above x what the pass ran / its time.  This is an HBM rate and must not exceed the copy ceiling.
+            sb = batch * ((iters - 1) * per_cw_pair + (first_cw if first_cw is not None else per_cw_pair))
+            hbm_stream["moved_GBps"] = sb / (hbm_stream["ms_per_step"] * 1e-3) / 1e9
+            hbm_stream["algorithmic_GBps"] = hbm_stream.pop("GBps")
+            hbm_stream["what"] = ("one tile group = the whole batch (%.0f MB of messages): every pass streams from HBM; moved_GBps = PMC "
+                                  "bytes per codeword-iteration (cache-resident geometry) x codeword-iterations / time" % hbm_stream["group_MB"])
+            out["roofline"]["hbm_streaming"] = hbm_stream
+            out["roofline"]["hbm_frac"] = hbm_stream["moved_GBps"] / HBM_PEAK_GBS
+        # measured ceilings of the two regimes, this GPU, this run: the in-place read-all / write-all stream an in-place
+        # BP pass is made of (a wave reads 51 consecutive 256-B rows and writes them back), at the size of a cache-resident
+        # tile group and far beyond the cache
+        try:
+            group_bytes = 4.0 * E * swept * lanes
+            out["roofline"]["cache_ceiling_GBps"] = lib.measure_rmw_stream(int(group_bytes), 51, 50)
+            out["roofline"]["cache_ceiling_what"] = ("in-place read-all / write-all stream (51 rows of 256 B per wave) over %.0f MB = the "
+                                                     "tile group's message array: the Infinity-Cache regime" % (group_bytes / 1e6))
+            out["roofline"]["hbm_rmw_ceiling_GBps"] = lib.measure_rmw_stream(int(16 * group_bytes), 51, 6)
+            out["roofline"]["frac_of_cache_ceiling"] = moved / out["roofline"]["cache_ceiling_GBps"]
+        except Exception as ex:  # (a measurement aid must not cost the run its line)
+            out["roofline"]["cache_ceiling_GBps"] = None
+            out["roofline"]["cache_ceiling_error"] = str(ex)
+        if tr:
+            out["roofline"]["traffic_all_kernels"] = tr["kernels"]
         if iso:
             ic = iso["ms_check"] / max(1, iso["launches_check"])
             iv = iso["ms_var"] / max(1, iso["launches_var"])
-            ig = {cname: 8.0 * E * iso["codewords"] / (ic * 1e-3) / 1e9, vname: 8.0 * E * iso["codewords_var"] / (iv * 1e-3) / 1e9}
+            scale_c, scale_v = iso["codewords"] / max(1, swept), iso["codewords_var"] / max(1, kt["codewords_var"])
             out["roofline"]["isolated"] = {
-                cname: {"codewords": iso["codewords"], "us": ic * 1e3, "algorithmic_GBps": ig[cname]},
-                vname: {"codewords": iso["codewords_var"], "us": iv * 1e3, "algorithmic_GBps": ig[vname]},
+                cname: {"codewords": iso["codewords"], "us": ic * 1e3, "moved_GBps": bytes_check * scale_c / (ic * 1e-3) / 1e9,
+                        "algorithmic_GBps": 8.0 * E * iso["codewords"] / (ic * 1e-3) / 1e9},
+                vname: {"codewords": iso["codewords_var"], "us": iv * 1e3, "moved_GBps": bytes_var * scale_v / (iv * 1e-3) / 1e9,
+                        "algorithmic_GBps": 8.0 * E * iso["codewords_var"] / (iv * 1e-3) / 1e9},
+                "what": "the same kernels alone on the chip, one series after the other over the whole tile group",
             }
-            out["roofline"]["dominant"]["frac"] = ig[dname] / HBM_PEAK_GBS  # the dominant kernel alone on the chip
+            out["roofline"]["dominant"]["frac_alone"] = out["roofline"]["isolated"][dname]["moved_GBps"] / HBM_PEAK_GBS
+        # self-check: nothing labelled a fraction of the HBM peak may exceed 1, and the HBM-streaming rate in moved bytes
+        # cannot beat this GPU's own copy ceiling by more than measurement noise
+        sc = {"frac_le_1": out["roofline"]["frac"] <= 1.0,
+              "whole_step_frac_le_1": out["roofline"]["whole_step"]["frac"] <= 1.0}
+        if hbm_stream:
+            sc["hbm_streaming_le_copy_ceiling"] = hbm_stream["moved_GBps"] <= 1.08 * copy_gbs
+        out["roofline"]["self_check"] = sc
+        if not all(sc.values()):
+            print(f"bench.py: roofline self-check failed: {sc}", file=sys.stderr)
         if args.parity_rows > 0:
-            out.update(parity_check(H, probs, msg, out_host, iters, method, min(args.parity_rows, batch)))
+            out.update(parity_check(H, probs, msg, out_host, iters, method, min(args.parity_rows, batch), swept, lanes))
             rc = 0 if out["parity_ok"] else 3
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(H, probs, msg, iters, method, E, args.cpu_seconds)
@@ -372,32 +437,44 @@ def gather_rank_times(torch, dist, ms, world, device):
     return [float(t.item()) for t in every]
 
 
-def parity_check(H, probs, msg, out_host, iters, method, rows):
-    """After the timed region: the first `rows` codewords of the timed output against the CPU oracle
-    (f32, same operation order; test infrastructure, never part of what is timed).  min-sum: every bit
-    equal.  tanh rule: bits equal wherever the oracle's posterior is outside the fp32 tolerance of
-    tests/helpers.compare (|L| > 2e-4 + 2e-4 |L|)."""
+def parity_check(H, probs, msg, out_host, iters, method, rows, swept=128, lanes=2):
+    """After the timed region: `rows` codewords of the timed output against the CPU oracle (f32, same operation order;
+    test infrastructure, never part of what is timed), spread over the FIRST, a MIDDLE and the LAST tile group of the
+    step and over every stream lane of each (a group's tiles are dealt to the lanes in order: `swept` codewords per
+    lane).  min-sum: every bit equal.  tanh rule: bits equal wherever the oracle's posterior is outside the fp32
+    tolerance of tests/helpers.compare (|L| > 2e-4 + 2e-4 |L|)."""
     from oracle import pyoracle
 
     om = {"min_sum": "min_sum", "product_sum": "tanh_complement"}[method]
-    threads = max(1, min(os.cpu_count() or 1, pyoracle.max_threads(), rows))
-    ref = pyoracle.bp_decode_batch(H, probs, msg[:rows], 1, iters, om, dtype="f32", threads=threads, early_exit=False)
-    diff = out_host[:rows] != ref["bits"]
+    batch = msg.shape[0]
+    group = max(64, swept * lanes)
+    ngroups = max(1, -(-batch // group))
+    starts = []
+    for g in sorted({0, ngroups // 2, ngroups - 1}):
+        for ln in range(lanes):
+            starts.append(min(batch - 1, g * group + ln * swept))
+    per = max(1, rows // len(starts))
+    idx = np.unique(np.concatenate([np.arange(st, min(batch, st + per)) for st in starts]))
+    threads = max(1, min(os.cpu_count() or 1, pyoracle.max_threads(), len(idx)))
+    ref = pyoracle.bp_decode_batch(H, probs, msg[idx], 1, iters, om, dtype="f32", threads=threads, early_exit=False)
+    diff = out_host[idx] != ref["bits"]
     if method != "min_sum":
         with np.errstate(invalid="ignore"):
             diff &= np.abs(ref["llr"]) > 2e-4 + 2e-4 * np.abs(ref["llr"])
-    return {"parity_checked": int(rows), "parity_mismatched_bits": int(diff.sum()), "parity_ok": bool(not diff.any()),
-            "parity_against": f"oracle f32 {om}, {iters} fixed iterations, first {rows} codewords of the timed output"}
+    return {"parity_checked": int(len(idx)), "parity_mismatched_bits": int(diff.sum()), "parity_ok": bool(not diff.any()),
+            "parity_against": f"oracle f32 {om}, {iters} fixed iterations, {per} codewords from each stream lane of the first, a "
+                              f"middle and the last tile group of the timed output (codewords {', '.join(str(x) for x in starts)} ...)"}
 
 
-def pmc_live(workload):
-    """roofline.traffic measured in THIS run: two rocprofv3 passes (FETCH_SIZE and WRITE_SIZE do not fit
-    one) of `bench.py --pmc-child` -- the same workload, one 256-codeword slice (the launch geometry of
-    the timed run: a cache-resident tile group per lane), 6 iterations -- started as child processes
-    BEFORE this process touches the GPU.  Units and gfx950 corrections as MI355X_MICROARCH.md's HBM
-    section prescribes (KiB; FETCH_SIZE x2: 128-byte read requests are tallied at 64 B; WRITE_SIZE x1;
-    re-verified on profiles/microbench/rmw_stream).  These are L2 <-> fabric bytes: Infinity-Cache hits
-    are counted, so they bound HBM bytes from above.  Returns None if anything goes wrong."""
+def rocprof_pmc_passes(passes, child_args, prefixes, skip=None, timeout=300):
+    """rocprofv3 counter passes of `bench.py --pmc-child <child_args>` -- short runs of the very workload, started as
+    child processes BEFORE this process touches the GPU (the profiler's preloaded library initialises the GPU in front
+    of the program it is given, so the program itself comes right after `--`: python3 bench.py, no wrapper).
+    `passes` = [(counter names of one pass, {counter: scale})]; counters that do not fit one pass go in separate ones
+    (FETCH_SIZE and WRITE_SIZE: MI355X_MICROARCH.md, PMC slots), never together with a trace domain other than
+    --kernel-trace.  Returns ({kernel base name: {counter: average per dispatch, "dispatches": n}}, the child's
+    geometry line) or (None, None) if anything goes wrong.  Per kernel the most common grid is taken: the schedule's
+    own steady-state launches."""
     import csv
     import re
     import shutil
@@ -406,56 +483,88 @@ def pmc_live(workload):
 
     exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
     if not os.path.exists(exe) or "rocprof" in os.environ.get("LD_PRELOAD", "") or os.environ.get("ROCPROFILER_REGISTER_FORCE_LOAD"):
-        return None  # no profiler, or this process is itself being profiled
+        return None, None  # no profiler, or this process is itself being profiled
     env = dict(os.environ, TMPDIR="/tmp")
-    per = {}
-    geom = None
+    per, geom = {}, None
     with tempfile.TemporaryDirectory(dir="/tmp") as td:
-        for counter, scale in (("FETCH_SIZE", 2048.0), ("WRITE_SIZE", 1024.0)):
-            cmd = [exe, "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", os.path.join(td, counter), "-o", "p",
-                   "--", sys.executable, os.path.abspath(__file__), "--pmc-child", "--workload", workload, "--batch", "256",
+        for idx, (counters, scales) in enumerate(passes):
+            out_dir = os.path.join(td, f"pass{idx}")
+            cmd = [exe, "--kernel-trace", "--pmc", *counters, "--output-format", "csv", "-d", out_dir, "-o", "p",
+                   "--", sys.executable, os.path.abspath(__file__), "--pmc-child", *child_args,
                    "--no-cpu-baseline", "--pmc", "off", "--parity-rows", "0"]
             try:
-                r = subprocess.run(cmd, env=env, cwd="/tmp", capture_output=True, text=True, timeout=240)  # (a pass takes 10-20 s)
+                r = subprocess.run(cmd, env=env, cwd="/tmp", capture_output=True, text=True, timeout=timeout)  # (a pass takes 10-20 s)
             except Exception:
-                return None
+                return None, None
             if r.returncode != 0:
-                return None
+                return None, None
             for ln in r.stdout.splitlines():
                 if ln.startswith("{") and "pmc_child" in ln:
                     geom = json.loads(ln)
             path = None
-            for root, _, files in os.walk(os.path.join(td, counter)):
+            for root, _, files in os.walk(out_dir):
                 for f in files:
                     if f.endswith("counter_collection.csv"):
                         path = os.path.join(root, f)
             if not path:
-                return None
-            tot, cnt = defaultdict(float), defaultdict(int)
+                return None, None
+            tot, cnt = defaultdict(lambda: defaultdict(float)), defaultdict(lambda: defaultdict(int))
             with open(path) as fh:
                 for row in csv.DictReader(fh):
-                    if row["Counter_Name"] != counter:
+                    c = row["Counter_Name"]
+                    if c not in counters:
                         continue
                     name = re.sub(r"^void ", "", row["Kernel_Name"].replace("(anonymous namespace)::", "")).split("(")[0]
-                    if not name.startswith(("k_var", "k_check")) or re.search(r"^k_check[^<]*<[^,>]+, true", name):
-                        continue  # (FIRST = true: the first iteration reads the priors, not the messages)
+                    if not name.startswith(prefixes) or (skip and re.search(skip, name)):
+                        continue
                     base = name.split("<")[0]
                     key = (base[:-2] if base.endswith("_x") else base, row["Grid_Size"])
-                    tot[key] += float(row["Counter_Value"]) * scale
-                    cnt[key] += 1
+                    tot[key][c] += float(row["Counter_Value"]) * scales.get(c, 1.0)
+                    cnt[key][c] += 1
             best = {}
-            for (name, grid), n in cnt.items():  # the most common grid = the schedule's own launches
+            for (name, grid), c in cnt.items():
+                n = max(c.values())
                 if name not in best or n > best[name][1]:
-                    best[name] = (tot[(name, grid)] / n, n)
-            for name, (b, n) in best.items():
-                per.setdefault(name, {})[counter] = b
-                per[name]["dispatches"] = n
+                    best[name] = (grid, n)
+            for name, (grid, n) in best.items():
+                d = per.setdefault(name, {})
+                for c in tot[(name, grid)]:
+                    d[c] = tot[(name, grid)][c] / cnt[(name, grid)][c]
+                d["dispatches"] = n
     if not geom or not per:
+        return None, None
+    return per, geom
+
+
+def pmc_live(workload, batch=256, extra=()):
+    """roofline.traffic measured in THIS run: two rocprofv3 passes (FETCH_SIZE and WRITE_SIZE do not fit one) of
+    `bench.py --pmc-child` -- the same workload, one 256-codeword slice (the launch geometry of the timed run: a
+    cache-resident tile group per lane), 6 iterations.  Units and gfx950 corrections as MI355X_MICROARCH.md's HBM
+    section prescribes (KiB; FETCH_SIZE x2: 128-byte read requests are tallied at 64 B; WRITE_SIZE x1; re-verified on
+    profiles/microbench/rmw_stream).  These are L2 <-> fabric bytes: Infinity-Cache hits are counted, so they bound HBM
+    bytes from above.  Returns None if anything goes wrong."""
+    per, geom = rocprof_pmc_passes([(("FETCH_SIZE",), {"FETCH_SIZE": 2048.0}), (("WRITE_SIZE",), {"WRITE_SIZE": 1024.0})],
+                                   ["--workload", workload, "--batch", str(batch), *extra], ("k_var", "k_check"),
+                                   skip=r"^k_check[^<]*<[^,>]+, true, false")  # (FIRST = true: iteration 1 reads the priors, not the messages)
+    if not per:
         return None
     kernels = {k: {"fetch_bytes": v.get("FETCH_SIZE"), "write_bytes": v.get("WRITE_SIZE"),
                    "traffic_bytes": (v.get("FETCH_SIZE") or 0.0) + (v.get("WRITE_SIZE") or 0.0), "dispatches": v["dispatches"]}
                for k, v in per.items() if "FETCH_SIZE" in v and "WRITE_SIZE" in v}
-    return {"codewords_per_launch": geom["codewords_per_launch"], "kernels": kernels}
+    return {"workload": workload, "codewords_per_launch": geom["codewords_per_launch"], "kernels": kernels,
+            "source": "live rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this run"}
+
+
+def sq_live(workload, batch):
+    """q-ary workloads: ONE rocprofv3 pass of SQ counters over a short child run -- what the check kernel really
+    ISSUED (SQ_INSTS_VALU: wave-level VALU instructions; SQ_ACTIVE_INST_VALU / SQ_BUSY_CYCLES / SQ_WAVE_CYCLES in
+    quad-cycles), beside the reference-operation count the roofline line is defined on."""
+    per, geom = rocprof_pmc_passes([(("SQ_WAVES", "SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_BUSY_CYCLES", "SQ_WAVE_CYCLES",
+                                      "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY"), {})],
+                                   ["--workload", workload, "--batch", str(batch)], ("k_q_",))
+    if not per:
+        return None
+    return {"kernels": per, "batch": geom.get("batch"), "source": "live rocprofv3 --pmc SQ_* pass of this run"}
 
 
 def self_launch(args):
@@ -614,6 +723,14 @@ def qary_bench(args, S, rank, world, dist, backend, local, iters):
     def step():
         dec.min_sum_batch_device(*[t.data_ptr() for t in d_in], batch, d_out.data_ptr(), stream=stream)
 
+    if args.pmc_child:  # what the SQ counter pass profiles: two calls, nothing else
+        with np.errstate(divide="ignore"):
+            step()
+            step()
+        torch.cuda.synchronize()
+        print(json.dumps({"pmc_child": True, "batch": batch}), flush=True)
+        dec.close()
+        return
     with np.errstate(divide="ignore"):
         for _ in range(max(1, args.warmup)):
             step()
@@ -666,6 +783,7 @@ def qary_bench(args, S, rank, world, dist, backend, local, iters):
                 "bound": "valu", "kernel": kt["check_kernel"], "unit": "Tops/s",
                 "achieved": ops * batch / (ms_check * 1e-3) / 1e12, "peak": VALU_PEAK_OPS / 1e12,
                 "frac": ops * batch / (ms_check * 1e-3) / VALU_PEAK_OPS, "traffic": None,
+                "frac_is": "REFERENCE operations (a derived count, below) / time / peak; what the kernel really issued: `executed`",
                 "reference_ops_per_launch": ops * batch, "assignments_per_launch": assignments * batch,
                 "what": "reference-ops = 3k per enumerated assignment of a degree-k check (k adds, k subtractions, k minima: "
                         "decoder.rs:600-627), Q^(k-1) assignments per check; achieved = that count / the check kernel's "
@@ -675,6 +793,22 @@ def qary_bench(args, S, rank, world, dist, backend, local, iters):
                 "share_of_loop_time": kt["ms_check"] / max(kt["ms_loop"], 1e-9),
             },
         }
+        sq = getattr(args, "sq_live", None)
+        ck = (kt["check_kernel"] or "").split("<")[0]
+        if sq and sq.get("batch") == batch and ck in sq["kernels"]:
+            c = sq["kernels"][ck]
+            wc = c.get("SQ_WAVE_CYCLES") or 0.0
+            line["roofline"]["executed"] = {
+                "valu_wave_instructions_per_launch": c.get("SQ_INSTS_VALU"),
+                "executed_valu_frac": (c.get("SQ_INSTS_VALU") or 0.0) * 64.0 / (ms_check * 1e-3) / VALU_PEAK_OPS,
+                "instructions_per_reference_op": (c.get("SQ_INSTS_VALU") or 0.0) * 64.0 / max(ops * batch, 1.0),
+                "wave_cycle_shares": {"issuing_valu": (c.get("SQ_ACTIVE_INST_VALU") or 0.0) / wc, "parked_on_waitcnt": (c.get("SQ_WAIT_ANY") or 0.0) / wc,
+                                      "issue_stalled": (c.get("SQ_WAIT_INST_ANY") or 0.0) / wc} if wc else None,
+                "waves_per_launch": c.get("SQ_WAVES"), "dispatches_profiled": c.get("dispatches"), "source": sq["source"],
+                "what": "what the check kernel ISSUED: SQ_INSTS_VALU (wave-level VALU instructions, all 64 lanes counted whether "
+                        "active or not) x 64 / the un-profiled HIP-event launch time / the fp32 VALU lane-op peak -- the measured "
+                        "counterpart of `frac`, which divides the REFERENCE's operation count by the same time",
+            }
         if args.workload.startswith("criterion"):
             # point-mass channel outputs: almost every message entry is +inf and the reference enumerates finite
             # supports only (decoder.rs:281-401) -- a handful of assignments per check, nothing like Q^(k-1).  The call
@@ -866,20 +1000,17 @@ def mc_cpu_leg(H, probs, r4, E, iters, args, world):
     return out
 
 
-def pmc_traffic(workload, batch, swept, kernel):
-    """Bytes per launch of the dominant kernel from rocprofv3 PMC passes (FETCH_SIZE x2,
-    WRITE_SIZE x1 -- the gfx950 corrections of MI355X_MICROARCH.md, re-verified on
-    profiles/microbench), recorded under profiles/ for exactly this workload geometry.
-    Counters cannot be read from inside the process, so this is the committed measurement,
-    or None when the run's geometry differs from the profiled one."""
-    for path in (os.path.join(ROOT, "profiles", "r02", f"pmc_traffic_{workload}.json"),
-                 os.path.join(ROOT, "profiles", f"r01_pmc_traffic_{workload}.json")):
+def pmc_traffic(workload, swept):
+    """Fallback for roofline.traffic when this run cannot take counters itself (the process is being profiled, N > 1, no
+    rocprofv3): the per-kernel bytes of an earlier live run of exactly this launch geometry, committed under
+    profiles/ by `bench.py --pmc-save` (same format as pmc_live's result).  None when the geometry differs."""
+    for rnd in ("r04",):
+        path = os.path.join(ROOT, "profiles", rnd, f"pmc_traffic_{workload}.json")
         try:
             d = json.load(open(path))
-            if d["batch"] == batch and d["tile_group_codewords"] == swept:
-                for name, v in d["kernels"].items():  # name prefix; the steady-state instantiation (FIRST = false)
-                    if name.startswith(kernel) and not re.search(r"^k_check[^<]*<[^,>]+, true", name):
-                        return v["traffic_bytes"]
+            if d["codewords_per_launch"] == swept and d.get("kernels"):
+                d["source"] = f"profiles/{rnd}/pmc_traffic_{workload}.json (committed rocprofv3 --pmc passes of this launch geometry)"
+                return d
         except Exception:
             pass
     return None

@@ -99,8 +99,17 @@ int scaldpc_debug_live_blocks(int64_t *out);
 /* Fault injection (tests): the `countdown`-th allocation the library makes from now on (device or pinned host,
  * any handle, any thread) fails with SCALDPC_ENOMEM; 0 disarms.  Every entry point must then return an error
  * code, leave the handle either intact or refusing further calls (never decoding on half-updated state), and
- * scaldpc_*_destroy must still release everything (scaldpc_debug_live_blocks back at its starting value). */
+ * scaldpc_*_destroy must still release everything (scaldpc_debug_live_blocks back at its starting value).
+ * Opt-in: the injector exists only in a process started with SCALDPC_DEBUG=1 (read once); otherwise arming it
+ * returns SCALDPC_EINVAL and the allocator never consults the countdown. */
 int scaldpc_debug_fail_alloc(int32_t countdown);
+/* Measurement aid for bench.py (`roofline.cache_ceiling_GBps`): an in-place read-all / write-all stream over
+ * `bytes` of scratch device memory -- every wave reads `rows_per_wave` consecutive 256-B rows and writes them back,
+ * the access shape of an in-place BP pass -- `reps` launches between two HIP events on the NULL stream of the
+ * current device.  *gbps = read + written bytes per second.  At the size of a cache-resident tile group (209 MB on
+ * the HQC-128 graph) this is what the Infinity Cache sustains for this shape; far beyond 256 MiB, what HBM does.
+ * No reference counterpart (measurement only). */
+int scaldpc_measure_rmw_stream(int64_t bytes, int32_t rows_per_wave, int32_t reps, double *gbps);
 
 /* ------------------------------------------------------------------ binary BP */
 typedef struct scaldpc_bp scaldpc_bp;

@@ -47,6 +47,8 @@ def _declare(lib):
     lib.scaldpc_debug_live_blocks.restype = C.c_int
     lib.scaldpc_debug_fail_alloc.argtypes = [C.c_int32]
     lib.scaldpc_debug_fail_alloc.restype = C.c_int
+    lib.scaldpc_measure_rmw_stream.argtypes = [C.c_int64, C.c_int32, C.c_int32, p(C.c_double)]
+    lib.scaldpc_measure_rmw_stream.restype = C.c_int
     lib.scaldpc_bp_create.argtypes = [C.c_int32, C.c_int32, C.c_int64, vp, vp, p(vp)]
     lib.scaldpc_bp_set_channel_probs.argtypes = [vp, vp]
     lib.scaldpc_bp_decode_batch.argtypes = [
@@ -146,6 +148,15 @@ def live_blocks():
     check(load().scaldpc_debug_live_blocks(out))
     keys = ("device_blocks", "device_bytes", "pinned_blocks", "pinned_bytes", "idle_blocks", "idle_bytes")
     return dict(zip(keys, (int(v) for v in out)))
+
+
+def measure_rmw_stream(nbytes, rows_per_wave=51, reps=50):
+    """GB/s (read + written) of an in-place read-all / write-all stream over `nbytes` of scratch device memory, every
+    wave sweeping `rows_per_wave` consecutive 256-B rows: the access shape of an in-place BP pass (bench.py's
+    cache / HBM ceilings; a measurement aid, nothing the decode path calls)."""
+    out = C.c_double(0.0)
+    check(load().scaldpc_measure_rmw_stream(int(nbytes), int(rows_per_wave), int(reps), C.byref(out)))
+    return float(out.value)
 
 
 def ptr(a):

@@ -101,10 +101,12 @@ struct scaldpc_bp {
         *d_unsat = nullptr;
     int *d_iters = nullptr, *d_remaining = nullptr;
     int cap_remaining = 0;
-    // d_remaining holds REM_SLOTS rows of cap_remaining "codewords still running after iteration it" counters: every tile
+    // d_remaining holds rem_rows rows of cap_remaining "codewords still running after iteration it" counters: every tile
     // group of a call takes the next row (zeroed once per call, not once per group: a memset is a 5 us launch in the
-    // group's dependency chain); rem_slot = next free row, REM_SLOTS = all used (the next taker zeroes the array)
-    int rem_slot = 0;
+    // group's dependency chain); rem_slot = next free row, rem_rows = all used (the next taker zeroes the array).
+    // rem_rows follows the groups a call can run (at most REM_SLOTS): max_iter defaults to n, and 512 rows of n + 2
+    // counters were 44 MB -- allocated and cleared -- on an HQC-sized decoder that decodes ONE codeword.
+    int rem_slot = 0, rem_rows = 0;
     bool post_alloc = false;
     // host-I/O staging
     uint8_t *d_in = nullptr, *d_out_bits = nullptr, *d_out_conv = nullptr;
@@ -338,17 +340,23 @@ int ensure_workspace(scaldpc_bp *h, int T, int G, bool want_post, int max_iter)
         SC_TRY(dev_alloc(&h->d_post, (size_t)h->cap_tiles * h->ws_n * TW));
         h->post_alloc = true;
     }
-    (void)G;  // the message arrays are allocated by the path that uses them (ensure_msg / ensure_el)
-    if (max_iter + 2 > h->cap_remaining) {
+    // (the message arrays are allocated by the path that uses them: ensure_msg / ensure_el)
+    // rows of counters: one per tile group of the call, the compact levels' groups (fewer tiles each) included, + row 0
+    const int groups = (T + std::max(1, G) - 1) / std::max(1, G);
+    const int want_rows = std::min(REM_SLOTS, 2 * groups + 8);
+    if (max_iter + 2 > h->cap_remaining || want_rows > h->rem_rows) {
         dev_free(h->d_remaining);
         cached_free(h->h_remaining);
         h->h_remaining = nullptr;
         h->cap_remaining = 0;
-        SC_TRY(dev_alloc(&h->d_remaining, (size_t)REM_SLOTS * ((size_t)max_iter + 2)));
-        SC_TRY(cached_alloc((void **)&h->h_remaining, sizeof(int) * ((size_t)max_iter + 2), true));
-        h->cap_remaining = max_iter + 2;
+        h->rem_rows = 0;
+        const int len = std::max(max_iter + 2, h->cap_remaining), rows = std::max(want_rows, h->rem_rows);
+        SC_TRY(dev_alloc(&h->d_remaining, (size_t)rows * (size_t)len));
+        SC_TRY(cached_alloc((void **)&h->h_remaining, sizeof(int) * (size_t)len, true));
+        h->cap_remaining = len;
+        h->rem_rows = rows;
     }
-    h->rem_slot = REM_SLOTS;  // a new call: the first tile group that needs counters zeroes the array
+    h->rem_slot = h->rem_rows;  // a new call: the first tile group that needs counters zeroes the array
     return 0;
 }
 
@@ -356,8 +364,8 @@ int ensure_workspace(scaldpc_bp *h, int T, int G, bool want_post, int max_iter)
 // memset of their own; they run between tile groups on the same stream)
 int next_remaining_row(scaldpc_bp *h, hipStream_t s, int **row)
 {
-    if (h->rem_slot >= REM_SLOTS) {
-        SC_HIP(hipMemsetAsync(h->d_remaining, 0, sizeof(int) * (size_t)REM_SLOTS * h->cap_remaining, s));
+    if (h->rem_slot >= h->rem_rows) {
+        SC_HIP(hipMemsetAsync(h->d_remaining, 0, sizeof(int) * (size_t)h->rem_rows * h->cap_remaining, s));
         h->rem_slot = 1;  // (row 0 is the other paths')
     }
     *row = h->d_remaining + (size_t)h->rem_slot++ * h->cap_remaining;

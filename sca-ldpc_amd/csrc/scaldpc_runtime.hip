@@ -78,13 +78,23 @@ int poison(void *p, size_t bytes, bool pinned_host)
 CacheBypass::CacheBypass(bool on) : prev(tl_bypass) { tl_bypass = prev || on; }
 CacheBypass::~CacheBypass() { tl_bypass = prev; }
 
-// scaldpc_debug_fail_alloc (tests): the k-th allocation from now fails with SCALDPC_ENOMEM
+// scaldpc_debug_fail_alloc (tests): the k-th allocation from now fails with SCALDPC_ENOMEM.  The injector exists only in a
+// process started with SCALDPC_DEBUG=1 (read once): without it the export refuses and the allocator never looks at the
+// countdown, so no caller or stray thread of a production process can poison the shared library.
 std::atomic<int> fail_countdown{0};
+bool debug_enabled()
+{
+    static const bool on = [] {
+        const char *e = getenv("SCALDPC_DEBUG");
+        return e && *e && strcmp(e, "0") != 0;
+    }();
+    return on;
+}
 
 int cached_alloc(void **p, size_t bytes, bool pinned_host)
 {
     *p = nullptr;
-    if (fail_countdown.load(std::memory_order_relaxed) > 0 && fail_countdown.fetch_sub(1) == 1)
+    if (debug_enabled() && fail_countdown.load(std::memory_order_relaxed) > 0 && fail_countdown.fetch_sub(1) == 1)
         return fail(SCALDPC_ENOMEM, "allocation of %zu bytes failed: injected by scaldpc_debug_fail_alloc", bytes);
     bytes = (bytes + 255) / 256 * 256;
     int dev = -1;
@@ -295,7 +305,59 @@ int scaldpc_debug_live_blocks(int64_t *out)
 
 int scaldpc_debug_fail_alloc(int32_t countdown)
 {
+    if (!debug_enabled()) {
+        fail_countdown.store(0);
+        return countdown > 0 ? fail(SCALDPC_EINVAL, "scaldpc_debug_fail_alloc: start the process with SCALDPC_DEBUG=1 to arm the fault injector") : 0;
+    }
     fail_countdown.store(countdown > 0 ? countdown : 0);
+    return 0;
+}
+
+// ---- measurement aid: the in-place stream an in-place BP pass is made of ---------------------------------------------
+namespace {
+// each wave owns `rows` consecutive 256-B rows (64 lanes x 4 B): reads them all, then writes them all back -- the access
+// shape of an in-place check pass over a row of `rows` edges (profiles/microbench/rmw_stream.hip, dword form)
+__global__ __launch_bounds__(256) void k_rmw_stream(float *buf, size_t nrows, int rows)
+{
+    const size_t wave = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    const size_t r0 = wave * (size_t)rows;
+    if (r0 + rows > nrows) return;
+    float *p = buf + r0 * 64 + lane;
+    float acc = 0.0f;
+    for (int k = 0; k < rows; k++) acc += p[(size_t)k * 64];
+    for (int k = 0; k < rows; k++) p[(size_t)k * 64] = acc + (float)k;
+}
+}  // namespace
+
+int scaldpc_measure_rmw_stream(int64_t bytes, int32_t rows_per_wave, int32_t reps, double *gbps)
+{
+    if (!gbps || bytes < 256 || rows_per_wave < 1 || rows_per_wave > 4096 || reps < 1)
+        return fail(SCALDPC_EINVAL, "scaldpc_measure_rmw_stream: bad argument");
+    const size_t nrows = (size_t)bytes / 256 / rows_per_wave * rows_per_wave;
+    if (nrows == 0) return fail(SCALDPC_EINVAL, "scaldpc_measure_rmw_stream: buffer smaller than one wave's rows");
+    float *buf = nullptr;
+    SC_HIP(hipMalloc(&buf, nrows * 256));
+    hipEvent_t a = nullptr, b = nullptr;
+    hipError_t e = hipMemset(buf, 0, nrows * 256);
+    if (e == hipSuccess) e = hipEventCreate(&a);
+    if (e == hipSuccess) e = hipEventCreate(&b);
+    float ms = 0.0f;
+    if (e == hipSuccess) {
+        const dim3 grid((unsigned)((nrows / rows_per_wave + 3) / 4));
+        for (int i = 0; i < 3; i++) hipLaunchKernelGGL(k_rmw_stream, grid, dim3(256), 0, 0, buf, nrows, (int)rows_per_wave);
+        e = hipEventRecord(a, 0);
+        for (int i = 0; i < reps; i++) hipLaunchKernelGGL(k_rmw_stream, grid, dim3(256), 0, 0, buf, nrows, (int)rows_per_wave);
+        if (e == hipSuccess) e = hipEventRecord(b, 0);
+        if (e == hipSuccess) e = hipEventSynchronize(b);
+        if (e == hipSuccess) e = hipGetLastError();
+        if (e == hipSuccess) e = hipEventElapsedTime(&ms, a, b);
+    }
+    if (a) (void)hipEventDestroy(a);
+    if (b) (void)hipEventDestroy(b);
+    (void)hipFree(buf);
+    if (e != hipSuccess) return fail(SCALDPC_EHIP, "scaldpc_measure_rmw_stream: %s", hipGetErrorString(e));
+    *gbps = 2.0 * (double)nrows * 256.0 * reps / ((double)ms * 1e-3) / 1e9;
     return 0;
 }
 

@@ -9,6 +9,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 GOLDEN = os.path.join(ROOT, "tests", "golden")
+# the allocation fault injector (scaldpc_debug_fail_alloc) exists only in a process started with SCALDPC_DEBUG=1; the
+# library reads the variable once, so it is set before anything loads it (tests/test_abi.py checks the refusal without it)
+os.environ.setdefault("SCALDPC_DEBUG", "1")
 
 
 def pytest_configure(config):

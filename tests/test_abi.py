@@ -41,6 +41,24 @@ def test_errors_cross_the_boundary_as_codes_not_exceptions():
     assert rc == L.EINVAL
 
 
+def test_fault_injector_is_opt_in():
+    """scaldpc_debug_fail_alloc arms only in a process started with SCALDPC_DEBUG=1 (an always-compiled,
+    process-wide injector any caller could arm).  Without the variable the export refuses with SCALDPC_EINVAL."""
+    import subprocess
+    import sys
+
+    L = importlib.import_module("sca-ldpc_amd._lib")
+    code = ("import ctypes,sys;l=ctypes.CDLL(sys.argv[1]);l.scaldpc_last_error.restype=ctypes.c_char_p;"
+            "rc=l.scaldpc_debug_fail_alloc(3);print(rc, l.scaldpc_last_error().decode());print(l.scaldpc_debug_fail_alloc(0))")
+    env = {k: v for k, v in os.environ.items() if k != "SCALDPC_DEBUG"}
+    r = subprocess.run([sys.executable, "-c", code, L.SO_PATH], capture_output=True, text=True, env=env, timeout=120)
+    assert r.returncode == 0, r.stderr
+    first, second = r.stdout.strip().splitlines()
+    assert first.startswith(str(L.EINVAL)) and "SCALDPC_DEBUG=1" in first and second.strip() == "0"
+    r = subprocess.run([sys.executable, "-c", code, L.SO_PATH], capture_output=True, text=True, env=dict(env, SCALDPC_DEBUG="1"), timeout=120)
+    assert r.returncode == 0 and r.stdout.strip().splitlines()[0].startswith("0"), r.stdout + r.stderr
+
+
 def test_no_product_module_touches_the_oracle():
     """The product path must never import, load or call anything under oracle/."""
     pkg = os.path.join(ROOT, "sca-ldpc_amd")

@@ -140,7 +140,16 @@ def test_one_handle_with_growing_and_shrinking_calls_without_the_block_cache():
     assert r.returncode == 0 and "child ok" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
 
 
-def test_failed_append_leaves_a_refusing_handle_and_no_leak():
+@pytest.fixture
+def fail_alloc():
+    """The fault injector, disarmed again when the test ends -- however it ends: an armed countdown is process-wide."""
+    L = lib.load()
+    assert L.scaldpc_debug_fail_alloc(0) == 0
+    yield L.scaldpc_debug_fail_alloc
+    L.scaldpc_debug_fail_alloc(0)
+
+
+def test_failed_append_leaves_a_refusing_handle_and_no_leak(fail_alloc):
     """scaldpc_bp_append_rows with the k-th allocation failing (scaldpc_debug_fail_alloc), k = 1, 2, ...: the call
     returns an error code (MemoryError here), the handle then REFUSES further calls -- host mirrors and device arrays
     may disagree, decoding on them would be undefined -- and destroy still releases every block.  Once k is past the
@@ -176,16 +185,16 @@ def test_failed_append_leaves_a_refusing_handle_and_no_leak():
                 dec.append_rows(*rows(100, 150))
                 dec.decode_batch(part(150)[2])  # the row-parallel tables of the growable handle exist now
                 r0 = 150
-            L.scaldpc_debug_fail_alloc(k)
+            assert fail_alloc(k) == 0  # (armed: SCALDPC_DEBUG=1, tests/conftest.py)
             try:
                 dec.append_rows(*rows(r0, 300))
-                L.scaldpc_debug_fail_alloc(0)
+                fail_alloc(0)
                 got = dec.decode_batch(msg, want_llr=True)
                 for key in ("bits", "llr", "iters", "converged"):
                     assert np.array_equal(got[key], want[key]), (k, key)
                 succeeded += 1
             except MemoryError:
-                L.scaldpc_debug_fail_alloc(0)
+                fail_alloc(0)
                 failed += 1
                 with pytest.raises(Exception, match="unusable"):
                     dec.decode_batch(part(r0)[2])  # (the Python object still has the old block length)
