@@ -121,11 +121,13 @@ def main():
     # multi-GPU run uses one device per rank and backend nccl (= RCCL).
     if os.environ.get("BENCH_FORCE_DEVICE") is not None:
         local = int(os.environ["BENCH_FORCE_DEVICE"])
-    backend = os.environ.get("BENCH_BACKEND", "nccl")
     torch.cuda.set_device(local)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend, rank=rank, world_size=world)
+    # gloo first (barriers, fallback), then RCCL tried for the end-of-run gathers: a transport failure must not cost the
+    # run its line (sca-ldpc_amd/shard.py: Collectives)
+    shard = importlib.import_module("sca-ldpc_amd.shard")
+    coll = shard.Collectives(rank, world, device=torch.device("cuda", local), want=os.environ.get("BENCH_BACKEND", "nccl"))
+    if rank == 0 and coll.note:
+        print(f"bench.py: {coll.note}", file=sys.stderr)
 
     S = importlib.import_module("sca-ldpc_amd")
     bp = importlib.import_module("sca-ldpc_amd.bp")
@@ -135,7 +137,7 @@ def main():
 
     hqc, key, method, iters = WORKLOADS[args.workload]
     if args.workload in QARY_WORKLOADS:
-        return qary_bench(args, S, rank, world, dist, backend, local, iters)
+        return finish(coll, qary_bench(args, S, rank, world, coll, local, iters))
     rows = json.load(open(os.path.join(ROOT, "tests", "golden", "hqc_first_rows.json")))
     H, Hin, _ = S.codes.hqc_bench_graph(hqc, rows[key])
     N, omega = S.codes.HQC_PARAMS[hqc]
@@ -146,7 +148,7 @@ def main():
         msg, ys = trials.hqc_trials(Hin, omega, args.eps, batch, base_seed=2, first_index=rank * batch)
 
     if args.workload == "hqc128_mc":
-        return mc_sweep(args, S, bp, lib, trials, H, N, omega, R, E, probs, iters, method, rank, world, local, dist, backend)
+        return finish(coll, mc_sweep(args, S, bp, lib, trials, H, N, omega, R, E, probs, iters, method, rank, world, local, coll))
     if args.pmc_child:  # what the PMC passes profile: one cache-resident group's worth of launches, nothing else
         iters = 6
     dec = bp.bp_decoder(H, max_iter=iters, bp_method=method, channel_probs=probs)
@@ -164,8 +166,7 @@ def main():
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
+        coll.barrier()
         torch.cuda.synchronize()
 
     if args.pmc_child:
@@ -185,7 +186,7 @@ def main():
     dt = time.perf_counter() - t0
     per_rank_ms = None
     if world > 1:  # every rank's own time travels to rank 0 (a straggler must not hide behind the MAX)
-        per_rank_ms = gather_rank_times(torch, dist, dt / args.steps * 1e3, world, dev if backend == "nccl" else "cpu")
+        per_rank_ms = coll.gather_scalars(dt / args.steps * 1e3)
         dt = max(per_rank_ms) * args.steps / 1e3
 
     # the same kernels streaming from HBM: one tile group = the whole batch (far beyond the 256 MiB
@@ -235,11 +236,10 @@ def main():
     del src, dst
 
     # success statistics + the one end-of-run collective
-    shard = importlib.import_module("sca-ldpc_amd.shard")
     out_host = d_out.cpu().numpy()
     ok = trials.success(out_host, ys, N).astype(np.uint8)
-    ok_all = shard.gather_results(ok, batch * world, rank, world, device=dev if backend == "nccl" else None)  # RCCL all_gather
-    ranks_seen = shard.gather_results(np.array([rank], dtype=np.int32), world, rank, world, device=dev if backend == "nccl" else None)
+    ok_all = coll.gather(ok, batch * world)  # RCCL all_gather (gloo if RCCL did not come up)
+    ranks_seen = coll.gather(np.array([rank], dtype=np.int32), world)
     succ = float(ok_all.mean())
     conv = float(d_conv.float().mean().item())
 
@@ -276,6 +276,8 @@ def main():
                 "tile_group": args.tile_group,
             },
             "rccl_ranks": int(len(set(ranks_seen.tolist()))),  # ranks the end-of-run all_gather saw
+            "collective_backend": coll.backend,  # "nccl" = RCCL; "gloo" = RCCL did not come up (collective_note says why); "none" = one rank
+            "collective_note": coll.note or None,
             "codewords_per_s": total_cw / dt,
             "whole_job_algorithmic_GBps": 16.0 * E * iters * total_cw / dt / 1e9,
             "decode_success_rate": succ,
@@ -423,18 +425,19 @@ def main():
             out["cpu_baseline"] = cpu_baseline(H, probs, msg, iters, method, E, args.cpu_seconds)
         print(json.dumps(out), flush=True)
     dec.close()
-    if world > 1:
-        dist.destroy_process_group()
+    return finish(coll, rc)
+
+
+def finish(coll, rc):
+    """Tear the process groups down and leave with `rc`.  A run that had to abandon an RCCL collective in flight (probe
+    timeout) leaves through os._exit: its teardown may never return, and its line is already printed."""
+    sys.stdout.flush()
+    sys.stderr.flush()
+    if coll.abandoned_collective:
+        os._exit(rc or 0)
+    coll.close()
     if rc:
         raise SystemExit(rc)
-
-
-def gather_rank_times(torch, dist, ms, world, device):
-    """all_gather of one float per rank: every rank's ms per step, in rank order."""
-    mine = torch.tensor([ms], dtype=torch.float64, device=device)
-    every = [torch.zeros_like(mine) for _ in range(world)]
-    dist.all_gather(every, mine)
-    return [float(t.item()) for t in every]
 
 
 def parity_check(H, probs, msg, out_host, iters, method, rows, swept=128, lanes=2):
@@ -578,7 +581,8 @@ def self_launch(args):
     if args.gpus <= 1 or "RANK" in os.environ:
         return
     # preflight: are there N GPUs?  (not for the gloo rehearsals, which put several ranks on one device or none)
-    if os.environ.get("BENCH_BACKEND", "nccl") == "nccl" and os.environ.get("BENCH_FORCE_DEVICE") is None:
+    if (os.environ.get("BENCH_BACKEND", "nccl") == "nccl" and os.environ.get("BENCH_FORCE_DEVICE") is None
+            and not (args.rendezvous_only and os.environ.get("SCALDPC_FORCE_NCCL_FAILURE") == "1")):  # (the CPU rehearsal of the fallback)
         have, how = visible_gpu_count()
         if have is not None and have < args.gpus:
             print(f"bench.py: --gpus {args.gpus} but this node shows {have} GPU(s) ({how}); nothing launched", file=sys.stderr)
@@ -587,7 +591,9 @@ def self_launch(args):
         so.bind(("127.0.0.1", 0))
         port = so.getsockname()[1]
     env = dict(os.environ)
-    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL across processes needs it on this driver
+    # dmabuf IPC: RCCL across processes needs it on this pool's driver.  Only a default: a value the environment already
+    # carries is left alone, and the value in effect is printed with the reason if RCCL does not come up (collective_note)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     env.setdefault("OMP_NUM_THREADS", "1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
@@ -633,24 +639,22 @@ def visible_gpu_count():
 
 
 def rendezvous_only(args, torch, dist, rank, world, local):
-    """The N > 1 launch path without the decode: process group up, one all_gather of the rank ids (the
-    same collective the end-of-run gather uses), rank 0 prints what it saw."""
-    backend = os.environ.get("BENCH_BACKEND", "nccl")
-    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    """The N > 1 launch path without the decode: process groups up (gloo, then RCCL tried: shard.Collectives), one
+    all_gather of the rank ids (the same collective the end-of-run gather uses), rank 0 prints what it saw and over
+    which backend."""
+    want = os.environ.get("BENCH_BACKEND", "nccl")
     dev = None
-    if backend == "nccl":
+    if want == "nccl" and torch.cuda.is_available():
         torch.cuda.set_device(int(os.environ.get("BENCH_FORCE_DEVICE", local)))
         dev = torch.device("cuda", torch.cuda.current_device())
-    if world > 1:
-        dist.init_process_group(backend, rank=rank, world_size=world)
     shard = importlib.import_module("sca-ldpc_amd.shard")
-    seen = shard.gather_results(np.array([rank], dtype=np.int32), world, rank, world, device=dev)
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+    coll = shard.Collectives(rank, world, device=dev, want=want)
+    seen = coll.gather(np.array([rank], dtype=np.int32), world)
+    coll.barrier()
     if rank == 0:
-        print(json.dumps({"rendezvous_only": True, "n_gpus": world, "backend": backend, "rccl_ranks": int(len(set(seen.tolist())))}),
-              flush=True)
+        print(json.dumps({"rendezvous_only": True, "n_gpus": world, "backend": coll.backend, "collective_note": coll.note or None,
+                          "rccl_ranks": int(len(set(seen.tolist())))}), flush=True)
+    return finish(coll, 0)
 
 
 def qary_case(workload, S, batch, rank):
@@ -697,7 +701,7 @@ def qary_reference_ops(g, cls, special):
     return float(((float(q) ** (deg - 1)) * 3 * deg).sum()), float((float(q) ** (deg - 1)).sum())
 
 
-def qary_bench(args, S, rank, world, dist, backend, local, iters):
+def qary_bench(args, S, rank, world, coll, local, iters):
     """BASELINE config 4 and its q-ary siblings through the simulate_rs-shaped classes: `--steps` calls of
     min_sum_batch on `--batch` codewords per rank, channel outputs resident in HBM when the timed region starts and
     symbols left there (the probability -> LLR conversion runs on the device, k_q_into_llr, inside the call); the
@@ -735,14 +739,12 @@ def qary_bench(args, S, rank, world, dist, backend, local, iters):
         for _ in range(max(1, args.warmup)):
             step()
         torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
+        coll.barrier()
         t0 = time.perf_counter()
         for _ in range(args.steps):
             step()
         torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
+        coll.barrier()
         dt = time.perf_counter() - t0
         out = d_out.cpu().numpy()
         # the same call as the PyO3 class takes it: host arrays in, symbols out (PCIe both ways) -- reported, never `value`
@@ -760,7 +762,7 @@ def qary_bench(args, S, rank, world, dist, backend, local, iters):
         dec.configure(timing=0)
     per_rank_ms = None
     if world > 1:
-        per_rank_ms = gather_rank_times(torch, dist, dt / args.steps * 1e3, world, torch.device("cuda", local) if backend == "nccl" else "cpu")
+        per_rank_ms = coll.gather_scalars(dt / args.steps * 1e3)
         dt = max(per_rank_ms) * args.steps / 1e3
     rc = 0
     if rank == 0:
@@ -774,6 +776,7 @@ def qary_bench(args, S, rank, world, dist, backend, local, iters):
             "config": {"workload": f"{what}, {iters} iterations, batch {batch}/GPU, pmf resident in HBM / symbols left in HBM "
                                    f"(probability->LLR conversion on the device, inside the timed call)", "batch_per_gpu": batch, "iters": iters},
             "codewords_per_s": batch * args.steps * world / dt, "calls_per_s": args.steps * world / dt,
+            "collective_backend": coll.backend, "collective_note": coll.note or None,
             "host_buffers": {"ms_per_step": dt_host * 1e3, "value": 2.0 * g.nnz * batch * iters / dt_host,
                              "what": "the same call with host arrays in and out, as the PyO3 class takes them (PCIe both ways included)"},
             "all_zero_rate": float((out == 0).all(axis=1).mean()),
@@ -837,10 +840,7 @@ def qary_bench(args, S, rank, world, dist, backend, local, iters):
             line["cpu_baseline"] = qary_cpu_baseline(oracle_call, inputs, iters, g, args.cpu_seconds)
         print(json.dumps(line), flush=True)
     dec.close()
-    if world > 1:
-        dist.destroy_process_group()
-    if rc:
-        raise SystemExit(rc)
+    return rc
 
 
 def qary_cpu_baseline(oracle_call, inputs, iters, g, budget_s):
@@ -873,7 +873,7 @@ def qary_cpu_baseline(oracle_call, inputs, iters, g, budget_s):
             "single_thread_value": 2.0 * g.nnz * iters / one, "single_thread_ms_per_call": one * 1e3}
 
 
-def mc_sweep(args, S, bp, lib, trials, H, N, omega, R, E, probs, iters, method, rank, world, local, dist, backend):
+def mc_sweep(args, S, bp, lib, trials, H, N, omega, R, E, probs, iters, method, rank, world, local, coll):
     """BASELINE config 5: `--trials` synthetic hqc.decode() trials sharded over the ranks by
     GLOBAL trial index (results independent of the GPU count), generated, decoded (early
     exit, max_iter 100) and compared on the device in sub-batches of `--mc-batch`; one gather
@@ -889,8 +889,7 @@ def mc_sweep(args, S, bp, lib, trials, H, N, omega, R, E, probs, iters, method, 
     for _ in range(args.warmup):  # untimed: workspace allocation, code-object load
         dec.mc_hqc_run(min(args.mc_batch, max(1, b - a)), omega, args.eps, seed=1, first_trial=0, early_exit=True)
     torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
+    coll.barrier()
     t0 = time.perf_counter()
     succ, its = [], []
     for s0 in range(a, b, args.mc_batch):
@@ -898,19 +897,17 @@ def mc_sweep(args, S, bp, lib, trials, H, N, omega, R, E, probs, iters, method, 
         succ.append(r["success"])
         its.append(r["iters"])
     torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
+    coll.barrier()
     dt = time.perf_counter() - t0
     succ = np.concatenate(succ) if succ else np.zeros(0, np.uint8)
     its = np.concatenate(its) if its else np.zeros(0, np.int32)
     dev = torch.device("cuda", local)
     per_rank_s = None
     if world > 1:
-        per_rank_s = [t / 1e3 for t in gather_rank_times(torch, dist, dt * 1e3, world, dev if backend == "nccl" else "cpu")]
+        per_rank_s = coll.gather_scalars(dt)
         dt = max(per_rank_s)
-    gdev = dev if backend == "nccl" else None
-    all_succ = shard.gather_results(succ, args.trials, rank, world, device=gdev)
-    all_its = shard.gather_results(its, args.trials, rank, world, device=gdev)
+    all_succ = coll.gather(succ, args.trials)
+    all_its = coll.gather(its, args.trials)
     rc = 0
     if rank == 0:
         total_iters = float(all_its.astype(np.int64).sum())
@@ -926,6 +923,7 @@ def mc_sweep(args, S, bp, lib, trials, H, N, omega, R, E, probs, iters, method, 
             "trials_per_s": args.trials / dt, "decode_success_rate": float(all_succ.mean()),
             "mean_iterations": float(all_its.mean()), "wall_s": dt,
             "success_checksum": shard.success_checksum(all_succ),
+            "collective_backend": coll.backend, "collective_note": coll.note or None,
         }
         if per_rank_s:
             line["per_rank_wall_s"] = per_rank_s
@@ -962,10 +960,7 @@ def mc_sweep(args, S, bp, lib, trials, H, N, omega, R, E, probs, iters, method, 
             rc = 0 if line.get("parity_ok", True) else 3
         print(json.dumps(line), flush=True)
     dec.close()
-    if world > 1:
-        dist.destroy_process_group()
-    if rc:
-        raise SystemExit(rc)
+    return rc
 
 
 def mc_cpu_leg(H, probs, r4, E, iters, args, world):

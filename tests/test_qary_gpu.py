@@ -1,6 +1,7 @@
 """GPU parity of the q-ary min-sum decoders (through the C ABI) vs the CPU oracle and vs
 the reference's own known-answer tests.  Hard decisions bit-exact."""
 import importlib
+import os
 
 import numpy as np
 import pytest
@@ -138,6 +139,50 @@ def test_kyber_shape_sample(oracle, golden):
     got = dec.min_sum_batch(pb, ps)
     ref = oracle.qary_special_batch(g, 2, 12, pb, ps, 2, threads=8)
     assert np.array_equal(got, ref)
+
+
+@pytest.mark.parametrize("batch", [1, 70])
+def test_registered_n1024r256sw6(oracle, golden, batch):
+    """The other registered Kyber size, DecoderN1024R256SW6 (simulate_rs/src/lib.rs:54-63: 256 x 1024, check blocks 1,
+    column degree 2 on the coefficient side, 1 on the row-sum side), on the H the reference's own generator makes for it
+    (`make_qary_qc_parity_check_matrix(256, 6, 3, RandomState(0), 1)`, fixture qary_qc_256_6_3_s0_cb1): every kernel
+    form -- tree walk (the default for B = 2 and six coefficient edges), generic wave-parallel, codeword per lane --
+    against the oracle (decoder_special.rs:471-617 restated), at batch 1 (the reference's one min_sum per call) and 70,
+    and once through the drop-in module the way kyber-side code reaches it: getattr(simulate_rs, name)(H, iters)
+    .min_sum(channel_output, channel_output_sum) with the row-sum pmf reversed as kyber.py:374-375 does (VERDICT r03
+    'missing' #2: the class had never been built on the GPU)."""
+    import sys
+
+    g = S.TannerGraph.from_coo(golden["generators"]["qary_qc_256_6_3_s0_cb1"])
+    assert (g.m, g.n) == (256, 1024)
+    H = g.to_dense(np.int8)
+    cdeg = np.abs(H).sum(axis=0)
+    assert set(cdeg[:768]) == {2} and set(cdeg[768:]) == {1} and set(np.abs(H).sum(axis=1)) == {7}
+    r2 = np.random.RandomState(20 + batch)
+    pb = r2.dirichlet(np.ones(5), size=(batch, 768)).astype(np.float32)
+    ps = r2.dirichlet(np.ones(25), size=(batch, 256)).astype(np.float32)
+    ref = oracle.qary_special_batch(g, 2, 12, pb, ps, 3, threads=8)
+    dec = qary.decoder_class("DecoderN1024R256SW6")(H, 3)
+    assert (dec.N, dec.R, dec.B, dec.BSUM, dec.DC) == (1024, 256, 2, 12, 7)
+    for wave, tree in ((-1, 1), (1, 1), (1, 0), (0, 0)):  # the library's choice, tree walk, generic wave kernel, lane kernel
+        dec.configure(wave=wave, tree=tree)
+        got = dec.min_sum_batch(pb, ps)
+        assert np.array_equal(got, ref), (wave, tree)
+    dec.close()
+    # through the drop-in module, the PyO3 surface (pydecoder.rs:96-145)
+    drop = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "sca-ldpc_amd", "dropin")
+    if drop not in sys.path:
+        sys.path.insert(0, drop)
+    import simulate_rs
+
+    cls = getattr(simulate_rs, "DecoderN1024R256SW6")
+    d2 = cls(H, 3)
+    out = d2.min_sum(pb[0], ps[0])
+    assert isinstance(out, list) and len(out) == 1024 and out == [int(x) for x in ref[0]]
+    # kyber.py:362-376 hands the row-sum pmf REVERSED (index q <-> -q): the decoder must see exactly what it is given
+    out_rev = d2.min_sum(pb[0], np.ascontiguousarray(ps[0][:, ::-1]))
+    ref_rev = oracle.qary_special_batch(g, 2, 12, pb[:1], np.ascontiguousarray(ps[:1, :, ::-1]), 3, threads=1)
+    assert out_rev == [int(x) for x in ref_rev[0]]
 
 
 def test_errors():

@@ -127,6 +127,53 @@ def test_bench_launches_its_own_ranks_from_a_plain_shell():
     assert line["n_gpus"] == 2 and line["rccl_ranks"] == 2 and line["backend"] == "gloo"
 
 
+def test_bench_falls_back_to_gloo_when_rccl_does_not_come_up():
+    """The first real multi-GPU run must not die on the transport: gloo comes up first, RCCL is tried
+    for the gathers, and if it fails on any rank -- forced here, as there is no GPU -- every rank gathers over gloo in
+    the same process and the line says so.  Exit code 0."""
+    import json
+
+    r = _run_bench("--gpus", "2", "--rendezvous-only", SCALDPC_FORCE_NCCL_FAILURE="1")  # BENCH_BACKEND defaults to nccl
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["rccl_ranks"] == 2 and line["backend"] == "gloo"
+    assert "nccl failed, gathers over gloo" in line["collective_note"]
+
+
+def _collectives_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["SCALDPC_FORCE_NCCL_FAILURE"] = "1"
+    coll = shard.Collectives(rank, world, device=None, want="nccl")
+    got = coll.gather(np.arange(3 if rank == 0 else 2, dtype=np.int32) + 10 * rank, 5)  # ragged: 3 + 2
+    times = coll.gather_scalars(1.5 + rank)
+    coll.barrier()
+    if rank == 0:
+        q.put((coll.backend, coll.note, got.tolist(), times))
+    coll.close()
+
+
+def test_collectives_fall_back_inside_the_process():
+    """shard.Collectives on two CPU ranks: the RCCL attempt fails on both (no GPU), the ranks agree over gloo and the
+    gathers -- ragged result vectors, per-rank scalars -- run there."""
+    import torch.multiprocessing as mp
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_collectives_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    backend, note, got, times = q.get(timeout=240)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert backend == "gloo" and "nccl failed" in note and got == [0, 1, 2, 10, 11] and times == [1.5, 2.5]
+
+
 def test_bench_forwards_its_childrens_failure():
     """No GPU here: the ranks refuse to run (no CPU fallback in the product path) and the launcher's
     exit code says so -- the self-launch must not swallow a failed rank."""
