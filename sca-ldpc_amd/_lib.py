@@ -11,7 +11,8 @@ import subprocess
 import sys
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-SO_PATH = os.path.join(_HERE, "libscaldpc.so")
+# (SCALDPC_SO: another build of the same library, for A/B measurements of compile-time variants)
+SO_PATH = os.environ.get("SCALDPC_SO") or os.path.join(_HERE, "libscaldpc.so")
 CSRC = os.path.join(_HERE, "csrc")
 
 OK, EINVAL, EHIP, ENOMEM, EPMF, ENOCONF, EDEGREE = range(7)

@@ -673,7 +673,7 @@ __device__ __forceinline__ void check_minsum_row_rec(const float *p, u64 synd_ma
     if (lane < DEG) mp = pos[lane];
     float x[DEG];
 #pragma unroll
-    for (int k = 0; k < DEG; k++) x[k] = p[(size_t)k * TW];
+    for (int k = 0; k < DEG; k++) x[k] = p[(size_t)k * TW];  // (plain loads: non-temporal ones cost 5-9 % and save no byte, profiles/r04/ab_rec_nontemporal.log)
     float m1 = FLT_MAX, m2 = FLT_MAX;
     const float fmax = FLT_MAX;
     u64 par = ((u64)(unsigned)rfl((int)(synd_mask >> 32)) << 32) | (unsigned)rfl((int)synd_mask);  // (uniform by construction: keep it on the scalar side)
