@@ -296,7 +296,7 @@ class BpDecoder:
 
     def configure(self, **knobs):
         """Tuning / test knobs of this decoder (include/scaldpc.h, scaldpc_bp_configure): path, split,
-        group_mb, el_max, el_fuse, compact_after, minsum_loop, var_order.  A new decoder takes its
+        group_mb, el_max, el_fuse, compact_after, var_order, first_fused, fuse_test, minsum_rec, rec_skip1.  A new decoder takes its
         defaults from the SCALDPC_* environment once, at construction; results never depend on them."""
         for k, v in knobs.items():
             _lib.check(self._lib.scaldpc_bp_configure(self._h, k.encode(), str(v).encode()))
