@@ -23,6 +23,9 @@ constexpr int ROW_CAP = 64;  // largest register-resident row degree (also the s
 #ifndef REC_CHUNK
 #define REC_CHUNK 8
 #endif
+#ifndef REC_KEEP_AG
+#define REC_KEEP_AG 18
+#endif
 
 __device__ __forceinline__ int rfl(int x) { return __builtin_amdgcn_readfirstlane(x); }
 
@@ -1397,29 +1400,36 @@ __device__ __forceinline__ float var_col_rec(float *tile_base, const float *__re
             rid[k] = rw16[k];
         }
 #pragma unroll
-        for (int k = VAR_INLINE; k < D; k++) {
-            eid[k] = ce1[k];
-            rid[k] = cr1[k];
-        }
+        for (int k = VAR_INLINE; k < D; k++) rid[k] = cr1[k];  // (their edge ids are wanted by the stores alone: fetched below)
     }
     // lane j's two masks (mask_col = the masks of the column's first position: a column's masks are contiguous)
     ulonglong2 mk = make_ulonglong2(0, 0);
     if ((int)lane < D) mk = mask_col[lane];
     const int nlo = (int)(unsigned)mk.x, nhi = (int)(unsigned)(mk.x >> 32), alo = (int)(unsigned)mk.y, ahi = (int)(unsigned)(mk.y >> 32);
     float mm[D], pp[D], m2[D];
-    u64 ag[D];
+    // The arg-min masks are wanted twice (execute mask of the second-magnitude load, select).  Up to REC_KEEP_AG edges they
+    // stay in SGPRs between the two; beyond, ids + rows + masks (4 SGPRs per edge) no longer fit the 102 and every excess
+    // mask became an SGPR spill, so the select of such a (rare) column re-reads them from the lane that holds them.
+    constexpr bool KEEP_AG = D <= REC_KEEP_AG;
+    u64 ag[KEEP_AG ? D : 1];
 #pragma unroll
     for (int k = 0; k < D; k++) mm[k] = sbase(rec_base + (size_t)rfl(rid[k]) * TW)[lane];
 #pragma unroll
     for (int k = 0; k < D; k++) {
-        ag[k] = ((u64)(unsigned)__builtin_amdgcn_readlane(ahi, k) << 32) | (unsigned)__builtin_amdgcn_readlane(alo, k);
+        const u64 agk = ((u64)(unsigned)__builtin_amdgcn_readlane(ahi, k) << 32) | (unsigned)__builtin_amdgcn_readlane(alo, k);
+        if constexpr (KEEP_AG) ag[k] = agk;
         asm("" : "=v"(m2[k]));  // (any value: read only where the load below has written it)
-        if (__builtin_amdgcn_inverse_ballot_w64(ag[k])) m2[k] = sbase(rec2_base + (size_t)rfl(rid[k]) * TW)[lane];
+        if (__builtin_amdgcn_inverse_ballot_w64(agk)) m2[k] = sbase(rec2_base + (size_t)rfl(rid[k]) * TW)[lane];
     }
 #pragma unroll
     for (int k = 0; k < D; k++) {
         const u64 ng = ((u64)(unsigned)__builtin_amdgcn_readlane(nhi, k) << 32) | (unsigned)__builtin_amdgcn_readlane(nlo, k);
-        const float a = __builtin_amdgcn_inverse_ballot_w64(ag[k]) ? m2[k] : mm[k];
+        u64 agk;
+        if constexpr (KEEP_AG)
+            agk = ag[k];
+        else
+            agk = ((u64)(unsigned)__builtin_amdgcn_readlane(ahi, k) << 32) | (unsigned)__builtin_amdgcn_readlane(alo, k);
+        const float a = __builtin_amdgcn_inverse_ballot_w64(agk) ? m2[k] : mm[k];
         mm[k] = __builtin_amdgcn_inverse_ballot_w64(ng) ? -a : a;
     }
     float temp = pr;
@@ -1428,6 +1438,10 @@ __device__ __forceinline__ float var_col_rec(float *tile_base, const float *__re
         pp[k] = temp;
         temp += mm[k];
     }
+    // the edge ids beyond the record's inline ones: held from the top they cost an SGPR per edge through the whole gather
+    // phase (with the rows and the masks: spills in the columns of 17+ edges)
+#pragma unroll
+    for (int k = VAR_INLINE; k < D; k++) eid[k] = ce1[k];
     float suf = 0.0f;
 #pragma unroll
     for (int k = D - 1; k >= 0; k--) {
