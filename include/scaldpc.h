@@ -281,8 +281,7 @@ int scaldpc_qary_into_llr(const float *pmf, int64_t rows, int32_t Q, uint32_t fl
  * once at creation): "wave" = -1 auto | 0 codeword per lane | 1 wave per (check, codeword);
  * "unroll" = 1 register-resident unrolled enumeration for small alphabets | 0 off;
  * "tree" = 1 tree-walk check kernel for the Kyber shape (B = 2, six coefficient edges per check) | 0 off
- * (SCALDPC_QARY_NO_TREE); "occ" = 1 | 2: waves per SIMD the unrolled enumeration kernel is compiled for (default 2; 3 and 4 measured slower,
- * SCALDPC_QARY_OCC; A/B knob); "timing" = 1: bracket the launches of a call with HIP events (scaldpc_qary_last_timing). */
+ * (SCALDPC_QARY_NO_TREE); "timing" = 1: bracket the launches of a call with HIP events (scaldpc_qary_last_timing). */
 int scaldpc_qary_configure(scaldpc_qary *h, const char *key, const char *value);
 /* Measurement aid for bench.py (the q-ary counterpart of scaldpc_bp_time_kernels): after
  * scaldpc_qary_configure(h, "timing", "1"), every check-node and variable-node launch of a call is bracketed by

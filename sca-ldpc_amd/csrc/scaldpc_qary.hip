@@ -413,7 +413,6 @@ struct QEnum<Q, K, K - 2, D...> {
             constexpr int ql = dl(q) + B;
             const float s2 = (S + A[K - 2][q]) + A[K - 1][ql];
             S2[slot(q)] = s2;
-            nconf += finite_f(s2) ? 1 : 0;
             Bt[K - 2][q] = vmin(s2 - A[K - 2][q], Bt[K - 2][q]);    // these two digits are the assignment's own
             Bt[K - 1][ql] = vmin(s2 - A[K - 1][ql], Bt[K - 1][ql]);
         }
@@ -456,7 +455,6 @@ struct QEnum<Q, K, K - 1, D...> {
         if constexpr (dl >= -B && dl <= B) {
             constexpr int ql = dl + B;
             const float S2 = S + A[K - 1][ql];
-            nconf += finite_f(S2) ? 1 : 0;
             upd(A, Bt, S2, std::make_integer_sequence<int, K - 1>());
             Bt[K - 1][ql] = vmin(S2 - A[K - 1][ql], Bt[K - 1][ql]);
         }
@@ -481,9 +479,17 @@ __device__ __forceinline__ void q_check_unrolled(float *msg, int e0, long Bp, lo
             A[j][q] = msg[((size_t)(e0 + j) * Q + q) * Bp + b];
             Bt[j][q] = INFINITY;
         }
-    int nconf = 0;
+    int nconf = 0;  // (threaded through the recursion for its signature's sake; nothing counts per assignment any more)
     QEnum<Q, K, 0>::run(A, Bt, 0.0f, nconf);
-    if (nconf == 0) {
+    // "at least one configuration" (decoder.rs:618 asserts it) without a counter in the enumeration: an assignment with a
+    // finite sum S lowers beta[0][d_0] to the finite S - alpha[0][d_0], and nothing else ever makes an entry of beta[0]
+    // finite (candidates through a non-finite alpha are inf or NaN, which v_min never lets in) -- so no assignment counted
+    // <=> no finite entry in beta[0].  The per-assignment v_cmp_class + add-with-carry were 9 % of the kernel's VALU
+    // instructions and the source of its 306 SGPR spills (round 4).
+    bool any_conf = false;
+#pragma unroll
+    for (int q = 0; q < Q; q++) any_conf |= finite_f(Bt[0][q]);
+    if (!any_conf) {
         bool bad = false;
 #pragma unroll
         for (int j = 0; j < K; j++) {
@@ -500,12 +506,12 @@ __device__ __forceinline__ void q_check_unrolled(float *msg, int e0, long Bp, lo
         for (int q = 0; q < Q; q++) msg[((size_t)(e0 + j) * Q + q) * Bp + b] = Bt[j][q];
 }
 
-// grid (R, Bp/64), block 64.  OCC = waves per SIMD the register allocation aims at (amdgpu_waves_per_eu): left alone the
-// compiler spends 294 registers on the 108 KB of straight-line code (one wave per SIMD, no spill), and a launch of
-// 2400 waves (config 4: 150 checks x 1024 codewords) then takes THREE rounds of 1024 where 2.34 would do -- the time per
-// launch is a staircase in the batch size (37 / 53.5 / 69 / 84 us at 1650 / 2400 / 3300 / 4800 waves, measured).
-template <int Q, int KMAX, int OCC>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(OCC, OCC))) void k_q_check_unrolled(
+// grid (R, Bp/64), block 64.  Registers: 97 (Q = 3, DC = 7) / 115 (Q = 5, DC = 5) since round 4 -- four waves per SIMD.
+// Until then a per-assignment configuration counter (v_cmp_class into an SGPR pair + add-with-carry for each of the 729
+// assignments) had the compiler hold hundreds of masks: 294 registers, ONE wave per SIMD (two with a forced allocation
+// and spills), and config 4's 2400 waves ran in two rounds: 48.9 -> 30.9 us per launch without it (see q_check_unrolled).
+template <int Q, int KMAX>
+__global__ __launch_bounds__(64) void k_q_check_unrolled(
     const int *__restrict__ row_ptr, float *msg, long Bp, int batch, int *__restrict__ err)
 {
     const int c = blockIdx.x;
@@ -1068,7 +1074,6 @@ struct scaldpc_qary {
     // on the launch stream; scaldpc_qary_last_timing reads the sums.  Off by default: the product path records nothing.
     int kn_llr_tiled = 1;  // probability -> LLR conversion through an LDS tile (coalesced reads); A/B knob "llr_tiled"
     int kn_var_small = 1;  // register-resident variable update for Q = 3 / 5 / 7 / 15 and columns of at most 4 checks (A/B knob "var_small")
-    int kn_occ = 2;      // unrolled enumeration: waves per SIMD the kernel is compiled for (1 or 2; A/B knob "occ")
     int kn_timing = 0;
     std::vector<hipEvent_t> tev;
     float stat_ms_check = 0.f, stat_ms_var = 0.f, stat_ms_call = 0.f;
@@ -1173,7 +1178,6 @@ int qary_build(int R, int N, int B, int BSUM, bool special, const int8_t *H, int
     if (!rc && hipGetDevice(&h->device) != hipSuccess) rc = fail(SCALDPC_EHIP, "hipGetDevice failed");
     if (const char *e = getenv("SCALDPC_QARY_WAVE")) h->kn_wave = atoi(e) != 0;  // the environment is read once per handle
     if (getenv("SCALDPC_QARY_NO_UNROLL")) h->kn_unroll = 0;
-    if (const char *o = getenv("SCALDPC_QARY_OCC")) h->kn_occ = atoi(o) <= 1 ? 1 : 2;
     if (getenv("SCALDPC_QARY_NO_TREE")) h->kn_tree = 0;
     if (!rc && hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking) != hipSuccess)
         rc = fail(SCALDPC_EHIP, "hipStreamCreate failed");
@@ -1301,14 +1305,14 @@ int qary_run(scaldpc_qary *h, const float *pmf_b, const float *pmf_s, int batch,
     for (int it = 1; it <= iters; it++) {
         if (timing) SC_HIP(hipEventRecord(h->tev[2 * (it - 1)], s));
         if (h->E) {
-#define QUNROLLED(QQ, KK, OCC)                                                                                    \
-    hipLaunchKernelGGL((k_q_check_unrolled<QQ, KK, OCC>), dim3(h->R, Bp / 64), dim3(64), 0, s, h->d_row_ptr, h->d_msg, Bp, \
+#define QUNROLLED(QQ, KK)                                                                                         \
+    hipLaunchKernelGGL((k_q_check_unrolled<QQ, KK>), dim3(h->R, Bp / 64), dim3(64), 0, s, h->d_row_ptr, h->d_msg, Bp, \
                        batch, h->d_err)
             if (unrolled == 3) {
-                if (h->kn_occ == 1) QUNROLLED(3, 7, 1); else QUNROLLED(3, 7, 2);
+                QUNROLLED(3, 7);
             } else if (unrolled == 5) {
-                if (h->kn_occ == 1) QUNROLLED(5, 5, 1); else QUNROLLED(5, 5, 2);
-            }  // (3 and 4 waves per SIMD were measured and lost: profiles/r03/ab_qary_occ.log; not compiled in)
+                QUNROLLED(5, 5);
+            }
 #undef QUNROLLED
             else if (h->special && tree_nb) {
                 // the Kyber shape: tree walk for the rows of 6 coefficient edges, the generic wave kernel for any others
@@ -1476,8 +1480,6 @@ int scaldpc_qary_configure(scaldpc_qary *h, const char *key, const char *value)
         h->kn_llr_tiled = atoi(value) != 0;
     else if (!strcmp(key, "var_small"))
         h->kn_var_small = atoi(value) != 0;
-    else if (!strcmp(key, "occ"))
-        h->kn_occ = atoi(value) <= 1 ? 1 : 2;
     else
         return fail(SCALDPC_EINVAL, "unknown knob %s", key);
     return 0;

@@ -20,8 +20,8 @@ qary = importlib.import_module("sca-ldpc_amd.qary")
           suppress_health_check=list(HealthCheck))
 @given(R=st.integers(2, 10), N=st.integers(6, 24), dc=st.integers(2, 5), B=st.integers(1, 3),
        batch=st.sampled_from([1, 3, 40, 70, 300]), iters=st.integers(1, 6), seed=st.integers(0, 9999),
-       zero_frac=st.sampled_from([0.0, 0.1]), occ=st.integers(1, 4), wave=st.sampled_from([-1, 0, 1]), var_small=st.integers(0, 1), llr_tiled=st.integers(0, 1))
-def test_random_qary_instances(oracle, R, N, dc, B, batch, iters, seed, zero_frac, occ, wave, var_small, llr_tiled):
+       zero_frac=st.sampled_from([0.0, 0.1]), wave=st.sampled_from([-1, 0, 1]), var_small=st.integers(0, 1), llr_tiled=st.integers(0, 1))
+def test_random_qary_instances(oracle, R, N, dc, B, batch, iters, seed, zero_frac, wave, var_small, llr_tiled):
     rng = np.random.RandomState(seed)
     Q = 2 * B + 1
     H = np.zeros((R, N), dtype=np.int8)
@@ -37,7 +37,7 @@ def test_random_qary_instances(oracle, R, N, dc, B, batch, iters, seed, zero_fra
         pmf /= pmf.sum(axis=2, keepdims=True)
     name = f"DecoderN{N}R{R}V{max(1, int(g.col_degrees().max()))}C{int(g.row_degrees().max())}B{B}"
     dec = qary.decoder_class(name)(H, iters)
-    dec.configure(occ=occ, wave=wave, var_small=var_small, llr_tiled=llr_tiled)  # kernel-form knobs: the compiled occupancy of the unrolled kernel, wave / lane mode -- invisible
+    dec.configure(wave=wave, var_small=var_small, llr_tiled=llr_tiled)  # kernel-form knobs: wave / lane mode, register-resident variable update, tiled conversion -- invisible
     with np.errstate(divide="ignore"):
         try:
             ref = oracle.qary_min_sum_batch(g, Q, pmf, iters, threads=4)
