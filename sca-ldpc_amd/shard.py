@@ -51,7 +51,9 @@ class Collectives:
         try:
             if device is None or not torch.cuda.is_available():
                 raise RuntimeError("no GPU visible to this rank")
-            grp = dist.new_group(backend="nccl", timeout=datetime.timedelta(seconds=600))
+            # (the communicator is built inside the first collective, a blocking call: the group's own timeout bounds that
+            # part, the deadline below the collective itself)
+            grp = dist.new_group(backend="nccl", timeout=datetime.timedelta(seconds=max(120.0, 2 * probe_timeout_s)))
             if os.environ.get("SCALDPC_FORCE_NCCL_FAILURE") == "1":
                 raise RuntimeError("forced by SCALDPC_FORCE_NCCL_FAILURE=1")
             t = torch.ones(1, device=device, dtype=torch.int32)
