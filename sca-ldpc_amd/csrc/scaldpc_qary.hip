@@ -348,29 +348,50 @@ __global__ void k_q_special_check(const int *__restrict__ row_ptr, float *msg, i
 // right through the recursion (the partial sum of the first j digits is shared by all
 // assignments below it: the same additions in the same order as decoder.rs:600-610, fewer of
 // them).  No finite-support filter is needed: an assignment through a non-finite alpha has
-// S = inf or NaN, its candidates S - alpha_j are inf or NaN, and fminf never lets those
-// lower a minimum -- exactly the assignments FiniteDValueIterator / `cfg.sum.is_finite()`
-// (decoder.rs:281-401, 612) would have skipped.
+// S = inf or NaN, and v_min never lets those lower a minimum -- exactly the assignments
+// FiniteDValueIterator / `cfg.sum.is_finite()` (decoder.rs:281-401, 612) would have skipped.
+//
+// MIN-MARGINALS OF S, ONE SUBTRACTION PER OUTPUT (round 4).  The reference computes, for every edge j and symbol d,
+//     beta_j[d] = min over the assignments with d_j = d of fl(S - alpha_j[d])          (decoder.rs:621-627)
+// with alpha_j[d] the SAME number in every candidate.  x -> fl(x - a) is monotone non-decreasing (exact subtraction is,
+// and so is rounding), so the minimum of the candidates is the candidate of the minimum:
+//     beta_j[d] = fl( M_j[d] - alpha_j[d] ),   M_j[d] = min over those assignments of S      -- bit for bit.
+// (A minimum that stays +inf -- no assignment with a finite sum through (j, d) -- gives beta = +inf without forming
+// inf - inf; a finite M implies a finite alpha_j[d], which is one of its summands.)  The enumeration therefore only
+// folds sums: every node of the digit tree returns the minimum of S over its subtree, the node for digit q of edge J
+// lowers M[J][q] with it, and the K subtractions per assignment (+ K minima) of the reference's form -- 7 x 729 each
+// for config 4's checks, 3956 v_sub and 2973 v_min per row -- become Q x K subtractions per ROW and about three
+// minima per assignment.  The oracle keeps the reference's form; every q-ary parity test holds this one to it.
 // lane = codeword, thread = (check, codeword).
 // ---------------------------------------------------------------------------
+// minimum of N values, two per v_min3_f32 (min is exact and order-free)
+template <int N>
+__device__ __forceinline__ float fold_min(const float (&v)[N])
+{
+    float m = v[0];
+#pragma unroll
+    for (int i = 1; i + 1 < N; i += 2) m = vmin3(m, v[i], v[i + 1]);
+    if constexpr (N % 2 == 0) m = vmin(m, v[N - 1]);
+    return m;
+}
+
 template <int Q, int K, int J, int... D>
 struct QEnum {
-    static __device__ __forceinline__ void run(const float (&A)[K][Q], float (&Bt)[K][Q], float S, int &nconf)
+    // S: the left-to-right sum of alpha over the digits D... chosen so far; returns min S over the subtree
+    static __device__ __forceinline__ float run(const float (&A)[K][Q], float (&M)[K][Q], float S)
     {
-        run_q(A, Bt, S, nconf, std::make_integer_sequence<int, Q>());
+        return run_q(A, M, S, std::make_integer_sequence<int, Q>());
     }
     template <int... Qs>
-    static __device__ __forceinline__ void run_q(const float (&A)[K][Q], float (&Bt)[K][Q], float S, int &nconf,
-                                                 std::integer_sequence<int, Qs...>)
+    static __device__ __forceinline__ float run_q(const float (&A)[K][Q], float (&M)[K][Q], float S, std::integer_sequence<int, Qs...>)
     {
-        (QEnum<Q, K, J + 1, D..., Qs>::run(A, Bt, S + A[J][Qs], nconf), ...);
+        const float sub[Q] = {QEnum<Q, K, J + 1, D..., Qs>::run(A, M, S + A[J][Qs])...};
+#pragma unroll
+        for (int q = 0; q < Q; q++) M[J][q] = vmin(M[J][q], sub[q]);
+        return fold_min(sub);
     }
 };
-// Last FREE digit (edge K-2; edge K-1's digit then follows from sum d = 0): the up to Q assignments that differ only in
-// these two digits share the digit of every earlier edge j, i.e. they all lower the SAME beta[j][d_j].  Their candidates
-// S2_q - alpha[j][d_j] (each S2_q built left to right as before: the reference's additions in the reference's order) are
-// folded into that minimum two at a time with v_min3_f32 -- min is exact and order-free, so the values are those of
-// one v_min per candidate, with a third fewer instructions on the K - 2 shared edges.
+// Last FREE digit (edge K-2; edge K-1's digit then follows from sum d = 0).
 template <int Q, int K, int... D>
 struct QEnum<Q, K, K - 2, D...> {
     static_assert(sizeof...(D) == K - 2, "digits of the edges before the last free one");
@@ -384,65 +405,37 @@ struct QEnum<Q, K, K - 2, D...> {
         for (int q = 0; q < Q; q++) n += ok(q) ? 1 : 0;
         return n;
     }
-    static __device__ __forceinline__ void run(const float (&A)[K][Q], float (&Bt)[K][Q], float S, int &nconf)
-    {
-        constexpr int NV = nvalid();
-        if constexpr (NV > 0) {
-            float S2[NV];
-            fill(A, Bt, S, nconf, S2, std::make_integer_sequence<int, Q>());
-            shared(A, Bt, S2, std::make_integer_sequence<int, K - 2>());
-        }
-    }
-    // valid q -> its slot among the valid ones
-    static constexpr int slot(int q)
+    static constexpr int slot(int q)  // valid q -> its slot among the valid ones
     {
         int n = 0;
         for (int t = 0; t < q; t++) n += ok(t) ? 1 : 0;
         return n;
     }
-    template <int... Qs>
-    static __device__ __forceinline__ void fill(const float (&A)[K][Q], float (&Bt)[K][Q], float S, int &nconf, float (&S2)[nvalid()],
-                                                std::integer_sequence<int, Qs...>)
+    static __device__ __forceinline__ float run(const float (&A)[K][Q], float (&M)[K][Q], float S)
     {
-        (one<Qs>(A, Bt, S, nconf, S2), ...);
+        constexpr int NV = nvalid();
+        if constexpr (NV > 0) {
+            float S2[NV];
+            fill(A, M, S, S2, std::make_integer_sequence<int, Q>());
+            return fold_min(S2);
+        }
+        return INFINITY;
+    }
+    template <int... Qs>
+    static __device__ __forceinline__ void fill(const float (&A)[K][Q], float (&M)[K][Q], float S, float (&S2)[nvalid()], std::integer_sequence<int, Qs...>)
+    {
+        (one<Qs>(A, M, S, S2), ...);
     }
     template <int q>
-    static __device__ __forceinline__ void one(const float (&A)[K][Q], float (&Bt)[K][Q], float S, int &nconf, float (&S2)[nvalid()])
+    static __device__ __forceinline__ void one(const float (&A)[K][Q], float (&M)[K][Q], float S, float (&S2)[nvalid()])
     {
         if constexpr (ok(q)) {
             constexpr int ql = dl(q) + B;
-            const float s2 = (S + A[K - 2][q]) + A[K - 1][ql];
+            const float s2 = (S + A[K - 2][q]) + A[K - 1][ql];  // the reference's additions in the reference's order
             S2[slot(q)] = s2;
-            Bt[K - 2][q] = vmin(s2 - A[K - 2][q], Bt[K - 2][q]);    // these two digits are the assignment's own
-            Bt[K - 1][ql] = vmin(s2 - A[K - 1][ql], Bt[K - 1][ql]);
+            M[K - 2][q] = vmin(M[K - 2][q], s2);
+            M[K - 1][ql] = vmin(M[K - 1][ql], s2);
         }
-    }
-    template <int... Js>
-    static __device__ __forceinline__ void shared(const float (&A)[K][Q], float (&Bt)[K][Q], const float (&S2)[nvalid()],
-                                                  std::integer_sequence<int, Js...>)
-    {
-        constexpr int dig[sizeof...(D) + 1] = {D..., 0};
-        (edge<Js, dig[Js]>(A, Bt, S2), ...);
-    }
-    template <int j, int dj>
-    static __device__ __forceinline__ void edge(const float (&A)[K][Q], float (&Bt)[K][Q], const float (&S2)[nvalid()])
-    {
-        constexpr int NV = nvalid();
-        float m = Bt[j][dj];
-        const float a = A[j][dj];
-        if constexpr (NV == 1) {
-            m = vmin(S2[0] - a, m);
-        } else if constexpr (NV == 2) {
-            m = vmin3(S2[0] - a, S2[1] - a, m);
-        } else if constexpr (NV == 3) {
-            m = vmin(S2[2] - a, vmin3(S2[0] - a, S2[1] - a, m));
-        } else if constexpr (NV == 4) {
-            m = vmin3(S2[2] - a, S2[3] - a, vmin3(S2[0] - a, S2[1] - a, m));
-        } else {
-            static_assert(NV == 5, "alphabets of up to 5 symbols are compiled (Q = 3, 5)");
-            m = vmin(S2[4] - a, vmin3(S2[2] - a, S2[3] - a, vmin3(S2[0] - a, S2[1] - a, m)));
-        }
-        Bt[j][dj] = m;
     }
 };
 // last edge: its digit is fixed by sum d = 0 (reached directly only when K = 1)
@@ -450,45 +443,35 @@ template <int Q, int K, int... D>
 struct QEnum<Q, K, K - 1, D...> {
     static constexpr int B = (Q - 1) / 2;
     static constexpr int dl = -((D - B) + ... + 0);
-    static __device__ __forceinline__ void run(const float (&A)[K][Q], float (&Bt)[K][Q], float S, int &nconf)
+    static __device__ __forceinline__ float run(const float (&A)[K][Q], float (&M)[K][Q], float S)
     {
         if constexpr (dl >= -B && dl <= B) {
             constexpr int ql = dl + B;
             const float S2 = S + A[K - 1][ql];
-            upd(A, Bt, S2, std::make_integer_sequence<int, K - 1>());
-            Bt[K - 1][ql] = vmin(S2 - A[K - 1][ql], Bt[K - 1][ql]);
+            M[K - 1][ql] = vmin(M[K - 1][ql], S2);
+            return S2;
         }
-    }
-    template <int... Js>
-    static __device__ __forceinline__ void upd(const float (&A)[K][Q], float (&Bt)[K][Q], float S2,
-                                               std::integer_sequence<int, Js...>)
-    {
-        constexpr int dig[sizeof...(D) + 1] = {D..., 0};
-        ((Bt[Js][dig[Js]] = vmin(S2 - A[Js][dig[Js]], Bt[Js][dig[Js]])), ...);
+        return INFINITY;
     }
 };
 
 template <int Q, int K>
 __device__ __forceinline__ void q_check_unrolled(float *msg, int e0, long Bp, long b, int *err)
 {
-    float A[K][Q], Bt[K][Q];
+    float A[K][Q], M[K][Q];
 #pragma unroll
     for (int j = 0; j < K; j++)
 #pragma unroll
         for (int q = 0; q < Q; q++) {
             A[j][q] = msg[((size_t)(e0 + j) * Q + q) * Bp + b];
-            Bt[j][q] = INFINITY;
+            M[j][q] = INFINITY;
         }
-    int nconf = 0;  // (threaded through the recursion for its signature's sake; nothing counts per assignment any more)
-    QEnum<Q, K, 0>::run(A, Bt, 0.0f, nconf);
-    // "at least one configuration" (decoder.rs:618 asserts it) without a counter in the enumeration: an assignment with a
-    // finite sum S lowers beta[0][d_0] to the finite S - alpha[0][d_0], and nothing else ever makes an entry of beta[0]
-    // finite (candidates through a non-finite alpha are inf or NaN, which v_min never lets in) -- so no assignment counted
-    // <=> no finite entry in beta[0].  The per-assignment v_cmp_class + add-with-carry were 9 % of the kernel's VALU
-    // instructions and the source of its 306 SGPR spills (round 4).
+    QEnum<Q, K, 0>::run(A, M, 0.0f);
+    // "at least one configuration" (decoder.rs:618 asserts it): an assignment with a finite sum makes M[0][d_0] finite, and
+    // nothing else does
     bool any_conf = false;
 #pragma unroll
-    for (int q = 0; q < Q; q++) any_conf |= finite_f(Bt[0][q]);
+    for (int q = 0; q < Q; q++) any_conf |= finite_f(M[0][q]);
     if (!any_conf) {
         bool bad = false;
 #pragma unroll
@@ -503,7 +486,8 @@ __device__ __forceinline__ void q_check_unrolled(float *msg, int e0, long Bp, lo
 #pragma unroll
     for (int j = 0; j < K; j++)
 #pragma unroll
-        for (int q = 0; q < Q; q++) msg[((size_t)(e0 + j) * Q + q) * Bp + b] = Bt[j][q];
+        for (int q = 0; q < Q; q++)
+            msg[((size_t)(e0 + j) * Q + q) * Bp + b] = finite_f(M[j][q]) ? M[j][q] - A[j][q] : INFINITY;  // (see above: one subtraction per output)
 }
 
 // grid (R, Bp/64), block 64.  Registers: 97 (Q = 3, DC = 7) / 115 (Q = 5, DC = 5) since round 4 -- four waves per SIMD.
@@ -750,8 +734,13 @@ __global__ __launch_bounds__(64) void k_q_special_check_wave(const int *__restri
 //   * the row-sum symbol of an assignment is base - (d_{NB-2} + d_{NB-1}): inside the unrolled block it
 //     moves through a window of 2 QB - 1 neighbouring symbols, which is loaded to / committed from
 //     registers once per block.
-// Per assignment: 2 adds + (NB + 1) subs + (NB + 1) mins = 16 VALU operations with register operands
-// (the generic wave kernel above: ~20 LDS accesses and ~100 integer / address operations).
+// Round 4: MIN-MARGINALS OF S (see QEnum above): x -> fl(x - a) is monotone, so
+//     beta_j[d] = min over assignments with d_j = d of fl(S - a_j[d]) = fl( (min over them of S) - a_j[d] )   bit for bit,
+// and the walk only folds sums: the unrolled block of QB d5-values lowers the two minima that belong to ITS digits
+// (d5's, the row-sum symbol's) with each S and hands ONE folded minimum up to d4's, d3's and the lane's digits.
+// Per assignment: 2 adds + 2 mins + (2 v_min3 + 1 v_min) / QB = ~4.7 VALU operations with register operands instead of
+// the 16 of the subtract-per-candidate form (the reference's own count: 21; the generic wave kernel above: ~20 LDS
+// accesses and ~100 integer / address operations); the NB * QB + QS subtractions happen once per ROW, at the commit.
 // wave = (check, codeword); LDS: Ab[NB*QB] + As[QS] floats (shared), per-lane tables
 // Bb[NB*QB][64] and Bs[QS][64]; the partial minima of the 64 lanes are combined at the end by a
 // transposed walk over the tables (exact), so the messages are bit-identical to the other kernels'.
@@ -792,16 +781,15 @@ __global__ __launch_bounds__(64) void k_q_special_check_tree(const int *__restri
     for (int j = 0; j < NL; j++) items *= QB;
     for (int t = lane; t < items; t += 64) {
         int dg[NL > 0 ? NL : 1];
-        float al[NL > 0 ? NL : 1], ml[NL > 0 ? NL : 1];
-        float P = 0.0f;
+        float ml[NL > 0 ? NL : 1];
+        float P = 0.0f, gl = INFINITY;  // gl: minimum of S over this work item (all assignments with the lane's digits)
         int dsum = 0, tt = t;
 #pragma unroll
         for (int j = 0; j < NL; j++) {
             dg[j] = tt % QB;
             tt /= QB;
-            al[j] = Ab[j * QB + dg[j]];
             ml[j] = Bb[(size_t)(j * QB + dg[j]) * 64 + lane];  // continue from the lane's table entry (see below)
-            P += al[j];  // ((0 + a_0) + a_1) + ...
+            P += Ab[j * QB + dg[j]];  // ((0 + a_0) + a_1) + ...
             dsum += dg[j] - B;
         }
         for (int d3 = 0; d3 < QB; d3++) {
@@ -821,43 +809,34 @@ __global__ __launch_bounds__(64) void k_q_special_check_tree(const int *__restri
                 aw[u] = As[top - u];
                 mw[u] = ps0[-(ptrdiff_t)u * 64];
             }
-            // The d5 values of one d4 are taken two at a time: the minima they SHARE (the leading digits', d3's and d4's)
-            // take both candidates in one v_min3_f32 -- min is exact and order-free, the candidates are the same
-            // floats (each S built left to right as before) -- a seventh fewer VALU instructions in this loop.
+            // Every S of the block (built left to right, the reference's additions in the reference's order) lowers the
+            // minimum of its own d5 and of its row-sum symbol; the QB sums of one d4 are folded (two per v_min3_f32) into
+            // ONE number for d4's minimum, the QB of those into one for d3's, and those into one for the lane's digits.
+            float g4[QB];
 #pragma unroll
             for (int d4 = 0; d4 < QB; d4++) {
                 const float P4 = P3 + A4[d4];
+                float Sv[QB];
 #pragma unroll
-                for (int d5 = 0; d5 + 1 < QB; d5 += 2) {
-                    const float Sa = (P4 + A5[d5]) + aw[d4 + d5], Sb = (P4 + A5[d5 + 1]) + aw[d4 + d5 + 1];
-#pragma unroll
-                    for (int j = 0; j < NL; j++) ml[j] = vmin3(ml[j], Sa - al[j], Sb - al[j]);
-                    m3 = vmin3(m3, Sa - a3, Sb - a3);
-                    b4[d4] = vmin3(b4[d4], Sa - A4[d4], Sb - A4[d4]);
-                    b5[d5] = vmin(b5[d5], Sa - A5[d5]);
-                    b5[d5 + 1] = vmin(b5[d5 + 1], Sb - A5[d5 + 1]);
-                    mw[d4 + d5] = vmin(mw[d4 + d5], Sa - aw[d4 + d5]);
-                    mw[d4 + d5 + 1] = vmin(mw[d4 + d5 + 1], Sb - aw[d4 + d5 + 1]);
+                for (int d5 = 0; d5 < QB; d5++) {
+                    Sv[d5] = (P4 + A5[d5]) + aw[d4 + d5];
+                    b5[d5] = vmin(b5[d5], Sv[d5]);
+                    mw[d4 + d5] = vmin(mw[d4 + d5], Sv[d5]);
                 }
-                if constexpr (QB % 2 == 1) {
-                    constexpr int d5 = QB - 1;
-                    const float S = (P4 + A5[d5]) + aw[d4 + d5];
-#pragma unroll
-                    for (int j = 0; j < NL; j++) ml[j] = vmin(ml[j], S - al[j]);
-                    m3 = vmin(m3, S - a3);
-                    b4[d4] = vmin(b4[d4], S - A4[d4]);
-                    b5[d5] = vmin(b5[d5], S - A5[d5]);
-                    mw[d4 + d5] = vmin(mw[d4 + d5], S - aw[d4 + d5]);
-                }
+                g4[d4] = fold_min(Sv);
+                b4[d4] = vmin(b4[d4], g4[d4]);
             }
-            *p3 = m3;
+            const float g3 = fold_min(g4);
+            *p3 = vmin(m3, g3);
+            gl = vmin(gl, g3);
 #pragma unroll
             for (int u = 0; u < WIN; u++) ps0[-(ptrdiff_t)u * 64] = mw[u];
         }
 #pragma unroll
-        for (int j = 0; j < NL; j++) Bb[(size_t)(j * QB + dg[j]) * 64 + lane] = ml[j];
+        for (int j = 0; j < NL; j++) Bb[(size_t)(j * QB + dg[j]) * 64 + lane] = vmin(ml[j], gl);
     }
-    // Combine the 64 lanes' partial minima (exact: min is order-free) and write c2v in place.  The tables
+    // Combine the 64 lanes' partial minima of S (exact: min is order-free), subtract the slot's alpha ONCE and write c2v in
+    // place (a minimum that stayed +inf -- no assignment through the slot -- gives +inf, not inf - inf).  The tables
     // are [slot][lane] in LDS: lane s takes slot s and walks the 64 entries of its row -- rotated by its own
     // index, so that the lanes of a wave hit 64 different banks -- instead of a butterfly of 6 cross-lane
     // shuffles per slot (each a dependent LDS-crossbar round trip: 480 of them per wave were half a wave's
@@ -880,7 +859,8 @@ __global__ __launch_bounds__(64) void k_q_special_check_tree(const int *__restri
             m2 = vmin(m2, row[(l + 2 + lane) & 63]);
             m3 = vmin(m3, row[(l + 3 + lane) & 63]);
         }
-        const float v = vmin(vmin(m0, m1), vmin(m2, m3));
+        const float mS = vmin(vmin(m0, m1), vmin(m2, m3));
+        const float v = finite_f(mS) ? mS - Ab[s] : INFINITY;  // (Ab and As are contiguous: slot s's alpha is Ab[s])
         if (s < NB * QB)
             msg[((size_t)(e0 + s / QB) * W + s % QB) * Bp + b] = v;
         else
