@@ -726,14 +726,15 @@ __global__ __launch_bounds__(64) void k_q_special_check_wave(const int *__restri
 // assignment (328 125 per check and iteration).  min is exact and order-free; the sum is not, so the
 // assignments are ENUMERATED (no min-plus shortcut), but they need not be enumerated independently:
 //   * the partial sums of a common prefix are shared (the same additions in the same order, fewer of
-//     them): a lane owns the first NB - 3 digits (its work items), loops over digit NB - 3 and unrolls
-//     the last two, so an assignment costs 2 additions instead of NB + 1;
-//   * a digit that is fixed during a loop needs no table: its running minimum is ONE register,
-//     committed to the per-lane table in LDS when the loop moves on (1 / QB^2 or less per assignment);
-//   * the two unrolled digits index their alpha / beta with compile-time indices (registers);
-//   * the row-sum symbol of an assignment is base - (d_{NB-2} + d_{NB-1}): inside the unrolled block it
-//     moves through a window of 2 QB - 1 neighbouring symbols, which is loaded to / committed from
-//     registers once per block.
+//     them): a lane owns the first NB - 3 digits (its work items) and unrolls the last three, so an
+//     assignment costs 2 additions instead of NB + 1;
+//   * the lane's own digits keep their running minima in per-lane LDS tables (dynamic indices), read and
+//     committed once per work item;
+//   * the three unrolled digits index their alpha / minima with compile-time indices: registers for the
+//     whole kernel;
+//   * the row-sum symbol of an assignment is T0 - (d_{NB-3} + d_{NB-2} + d_{NB-1}): inside a work item it
+//     moves through a window of 3 QB - 2 neighbouring symbols, which is loaded to / committed from
+//     registers once per item.
 // Round 4: MIN-MARGINALS OF S (see QEnum above): x -> fl(x - a) is monotone, so
 //     beta_j[d] = min over assignments with d_j = d of fl(S - a_j[d]) = fl( (min over them of S) - a_j[d] )   bit for bit,
 // and the walk only folds sums: the unrolled block of QB d5-values lowers the two minima that belong to ITS digits
@@ -751,13 +752,13 @@ __global__ __launch_bounds__(64) void k_q_special_check_tree(const int *__restri
                                                              long Bp)
 {
     static_assert(NB >= 3, "needs at least three coefficient edges");
-    constexpr int B = (QB - 1) / 2, NL = NB - 3, WIN = 2 * QB - 1;
+    constexpr int B = (QB - 1) / 2, NL = NB - 3, WIN = 3 * QB - 2;
     extern __shared__ unsigned char smem[];
     const int lane = threadIdx.x;
     const int QS = 2 * BSUM + 1;
     float *Ab = (float *)smem;               // [NB][QB]
     float *As = Ab + NB * QB;                // [QS]
-    float *Bb = As + QS;                     // [NB * QB][64]   per-lane tables of the digits (the last two rows only at the end)
+    float *Bb = As + QS;                     // [NB * QB][64]   per-lane tables of the digits (the unrolled digits' rows only at the end)
     float *Bs = Bb + (size_t)NB * QB * 64;   // [QS][64]
     const int c = blockIdx.x;
     const long b = blockIdx.y;
@@ -765,14 +766,17 @@ __global__ __launch_bounds__(64) void k_q_special_check_tree(const int *__restri
     if (nb != NB) return;
     for (int i = lane; i < NB * QB; i += 64) Ab[i] = msg[((size_t)(e0 + i / QB) * W + i % QB) * Bp + b];
     for (int i = lane; i < QS; i += 64) As[i] = msg[((size_t)(e0 + NB) * W + i) * Bp + b];
-    for (int i = 0; i < (NB - 2) * QB; i++) Bb[(size_t)i * 64 + lane] = INFINITY;
+    for (int i = 0; i < NL * QB; i++) Bb[(size_t)i * 64 + lane] = INFINITY;  // (the unrolled digits' rows are written at the end)
     for (int i = 0; i < QS; i++) Bs[(size_t)i * 64 + lane] = INFINITY;
     __syncthreads();
-    float A4[QB], A5[QB], b4[QB], b5[QB];  // the two unrolled digits: compile-time indices
+    // digits NB-3 .. NB-1 are unrolled (compile-time indices): their alphas and running minima are registers for the whole kernel
+    float A3[QB], A4[QB], A5[QB], b3[QB], b4[QB], b5[QB];
 #pragma unroll
     for (int q = 0; q < QB; q++) {
+        A3[q] = Ab[NL * QB + q];
         A4[q] = Ab[(NB - 2) * QB + q];
         A5[q] = Ab[(NB - 1) * QB + q];
+        b3[q] = INFINITY;
         b4[q] = INFINITY;
         b5[q] = INFINITY;
     }
@@ -788,30 +792,29 @@ __global__ __launch_bounds__(64) void k_q_special_check_tree(const int *__restri
         for (int j = 0; j < NL; j++) {
             dg[j] = tt % QB;
             tt /= QB;
-            ml[j] = Bb[(size_t)(j * QB + dg[j]) * 64 + lane];  // continue from the lane's table entry (see below)
+            ml[j] = Bb[(size_t)(j * QB + dg[j]) * 64 + lane];  // continue from the lane's table entry
             P += Ab[j * QB + dg[j]];  // ((0 + a_0) + a_1) + ...
             dsum += dg[j] - B;
         }
-        for (int d3 = 0; d3 < QB; d3++) {
-            const float a3 = Ab[NL * QB + d3];
-            const float P3 = P + a3;
-            // row-sum symbol of (.., d3, d4, d5): BSUM - (dsum + (d3-B) + (d4-B) + (d5-B)) = top - (d4 + d5)
-            const int top = BSUM - (dsum + d3 - B) + 2 * B;
-            // the running minima of this block START from the lane's table entries (read up front, together
-            // with the alpha window), so that the commit at the end is a plain store: no read-modify-write
-            // chain of LDS latencies behind the arithmetic
-            float *const p3 = &Bb[(size_t)(NL * QB + d3) * 64 + lane];
-            float *const ps0 = &Bs[(size_t)top * 64 + lane];
-            float m3 = *p3;
-            float aw[WIN], mw[WIN];
+        // Row-sum symbol of (.., d3, d4, d5): BSUM - (dsum + (d3-B) + (d4-B) + (d5-B)) = T0 - (d3 + d4 + d5): over the whole
+        // work item it moves through a window of 3 QB - 2 neighbouring symbols.  Their alphas and the lane's running minima
+        // are loaded ONCE per item and committed once (round 4: the window used to be re-loaded and committed for every d3 --
+        // 29 LDS operations per 25 assignments, which bound the kernel once the arithmetic had shrunk to ~5 operations per
+        // assignment).  The minima START from the lane's table entries, so the commit is a plain store.
+        const int T0 = BSUM - dsum + 3 * B;
+        float *const ps0 = &Bs[(size_t)T0 * 64 + lane];
+        float aw[WIN], mw[WIN];
 #pragma unroll
-            for (int u = 0; u < WIN; u++) {
-                aw[u] = As[top - u];
-                mw[u] = ps0[-(ptrdiff_t)u * 64];
-            }
-            // Every S of the block (built left to right, the reference's additions in the reference's order) lowers the
-            // minimum of its own d5 and of its row-sum symbol; the QB sums of one d4 are folded (two per v_min3_f32) into
-            // ONE number for d4's minimum, the QB of those into one for d3's, and those into one for the lane's digits.
+        for (int u = 0; u < WIN; u++) {
+            aw[u] = As[T0 - u];
+            mw[u] = ps0[-(ptrdiff_t)u * 64];
+        }
+        // Every S (built left to right, the reference's additions in the reference's order) lowers the minimum of its own d5
+        // and of its row-sum symbol; the QB sums of one d4 are folded (two per v_min3_f32) into ONE number for d4's minimum,
+        // the QB of those into one for d3's, and those into one for the lane's digits.
+#pragma unroll
+        for (int d3 = 0; d3 < QB; d3++) {
+            const float P3 = P + A3[d3];
             float g4[QB];
 #pragma unroll
             for (int d4 = 0; d4 < QB; d4++) {
@@ -819,19 +822,19 @@ __global__ __launch_bounds__(64) void k_q_special_check_tree(const int *__restri
                 float Sv[QB];
 #pragma unroll
                 for (int d5 = 0; d5 < QB; d5++) {
-                    Sv[d5] = (P4 + A5[d5]) + aw[d4 + d5];
+                    Sv[d5] = (P4 + A5[d5]) + aw[d3 + d4 + d5];
                     b5[d5] = vmin(b5[d5], Sv[d5]);
-                    mw[d4 + d5] = vmin(mw[d4 + d5], Sv[d5]);
+                    mw[d3 + d4 + d5] = vmin(mw[d3 + d4 + d5], Sv[d5]);
                 }
                 g4[d4] = fold_min(Sv);
                 b4[d4] = vmin(b4[d4], g4[d4]);
             }
             const float g3 = fold_min(g4);
-            *p3 = vmin(m3, g3);
+            b3[d3] = vmin(b3[d3], g3);
             gl = vmin(gl, g3);
-#pragma unroll
-            for (int u = 0; u < WIN; u++) ps0[-(ptrdiff_t)u * 64] = mw[u];
         }
+#pragma unroll
+        for (int u = 0; u < WIN; u++) ps0[-(ptrdiff_t)u * 64] = mw[u];
 #pragma unroll
         for (int j = 0; j < NL; j++) Bb[(size_t)(j * QB + dg[j]) * 64 + lane] = vmin(ml[j], gl);
     }
@@ -840,10 +843,13 @@ __global__ __launch_bounds__(64) void k_q_special_check_tree(const int *__restri
     // are [slot][lane] in LDS: lane s takes slot s and walks the 64 entries of its row -- rotated by its own
     // index, so that the lanes of a wave hit 64 different banks -- instead of a butterfly of 6 cross-lane
     // shuffles per slot (each a dependent LDS-crossbar round trip: 480 of them per wave were half a wave's
-    // life, profiles/r02/sq_counters_kyber_tree.json).  The two unrolled digits' register minima go through
-    // the table as well (rows NB-2 and NB-1 of Bb).
+    // life, profiles/r02/sq_counters_kyber_tree.json).  The three unrolled digits' register minima go through
+    // the table as well (rows NB-3 .. NB-1 of Bb).  (A two-phase combine over a table without those rows -- 10.2 KB of
+    // LDS per wave instead of 14.3, 15 waves per CU instead of 11 -- was measured and is SLOWER: 1.97 -> 2.08 ms per
+    // 256-codeword call, issue stalls 26 % -> 40 % of the wave cycles; profiles/r04/qary_min_marginals.log.)
 #pragma unroll
     for (int q = 0; q < QB; q++) {
+        Bb[(size_t)(NL * QB + q) * 64 + lane] = b3[q];
         Bb[(size_t)((NB - 2) * QB + q) * 64 + lane] = b4[q];
         Bb[(size_t)((NB - 1) * QB + q) * 64 + lane] = b5[q];
     }
