@@ -54,7 +54,7 @@
 extern "C" {
 #endif
 
-#define SCALDPC_VERSION 102
+#define SCALDPC_VERSION 103
 
 /* status codes */
 #define SCALDPC_OK 0

@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
     lib = L.load()  # raises if the HIP extension is missing: there is no fallback
     for fn in declared_functions():
         assert hasattr(lib, fn), f"{fn} declared in include/scaldpc.h but not exported"
-    assert lib.scaldpc_version() == 102
+    assert lib.scaldpc_version() == 103  # (round 4: scaldpc_measure_rmw_stream added, A/B knobs removed, fault injector opt-in)
 
 
 def test_errors_cross_the_boundary_as_codes_not_exceptions():
