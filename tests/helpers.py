@@ -164,7 +164,7 @@ COMPARED = {}  # call-site label -> [codewords compared with the float64 referen
 
 
 def check_reference_form(oracle, got, H, probs, x, kind, max_iter, early, *, min_fraction, threads=8, tol=1e-3, label=None,
-                         same_order64=None):
+                         same_order64=None, oracle32=None):
     """The independent check of every product-sum parity test: the HIP result against the float64
     probability-ratio recursion of the reference's package (oracle method 0) -- a different
     formulation in a different precision, so nothing here can mirror the device.  Compared on the
@@ -184,11 +184,19 @@ def check_reference_form(oracle, got, H, probs, x, kind, max_iter, early, *, min
     +-1 and turns "very likely" into "certain": harmless where the posterior is large too (both sides clamp), but a
     variable whose large messages CANCEL (+500 and -512: posterior -11.90 in the LLR form, N=873 W=6 omega=11 eps=0,
     found by the 1000-example soak) comes out as -inf in the ratio form.  The filter uses oracle results only, never
-    the device's, and the floor `min_fraction` still applies after it.  Returns the fraction compared."""
+    the device's, and the floor `min_fraction` still applies after it.  `oracle32` (the property tests): the f32 oracle's
+    result in the kernel's operation order -- what `compare` has just held the device to, NaN places included.  Codewords
+    whose float32 ORACLE has NaN posteriors where the float64 form has none are float32 SATURATION, not a formulation
+    matter: on a small graph dense with short cycles (32 checks on 10 variables, column degree ~11: found by the
+    3000-example soak of round 4) messages pass |L| = 87.3 within five iterations, become +-inf in float32, and
+    contradicting infinities sum to NaN, while float64 still carries finite numbers.  Such codewords are left out
+    (oracle results only again).  Returns the fraction compared."""
     with np.errstate(divide="ignore", invalid="ignore"):
         ref64 = oracle.bp_decode_batch(H, probs, x, kind, max_iter, "product_sum", dtype="f64", threads=threads,
                                        early_exit=early)
     keep = ref64["converged"].astype(bool) & (got["iters"] == ref64["iters"])
+    if oracle32 is not None:
+        keep &= (np.isnan(oracle32["llr"]) == np.isnan(ref64["llr"])).all(axis=1)
     if same_order64 is not None:
         keep &= (np.isnan(ref64["llr"]) == np.isnan(same_order64["llr"])).all(axis=1)
         with np.errstate(invalid="ignore"):

@@ -101,7 +101,7 @@ def test_random_instances(oracle, m, n, density, batch, method, received, early,
         # see test_the_reference_form_checks_compared_something.
         with np.errstate(divide="ignore", invalid="ignore"):
             check_reference_form(oracle, got, g, probs, x, 1 if received else 0, max_iter, early, min_fraction=0.0,
-                                 threads=4, tol=max(1e-3, 2.0 * tol), label="tiny", same_order64=same64)
+                                 threads=4, tol=max(1e-3, 2.0 * tol), label="tiny", same_order64=same64, oracle32=ref)
 
 
 @settings(max_examples=int(os.environ.get("SCALDPC_PROPERTY_EXAMPLES", "24")), deadline=None, derandomize=True,
@@ -159,7 +159,7 @@ def test_random_hqc_shaped_instances(oracle, N, W, rfrac, omega, eps, batch, met
         # rule may move a codeword's iteration count by one between float32 and float64, hence not 100 %)
         with np.errstate(divide="ignore", invalid="ignore"):
             check_reference_form(oracle, got, H, probs, msg, 1, max_iter, early, min_fraction=reference_floor(ref, 0.6),
-                                 threads=8, tol=max(1e-3, 2.0 * tol), label="hqc", same_order64=same64)
+                                 threads=8, tol=max(1e-3, 2.0 * tol), label="hqc", same_order64=same64, oracle32=ref)
 
 
 def test_the_reference_form_checks_compared_something():
