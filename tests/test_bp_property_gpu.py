@@ -26,8 +26,15 @@ def _progress():
 
 
 def _own_sensitivity(oracle, g, probs, x, kind, max_iter, method, early, ref):
-    """20x the largest relative move of the oracle's posteriors between float32 and float64 (same
-    operation order), never below the fixed fp32 tolerance 2e-4."""
+    """The tolerance of the tanh rule on graphs no decoder is meant for, from the ORACLE's own sensitivity (never the
+    device's results), never below the fixed fp32 tolerance 2e-4: the larger of
+      * 20x the largest relative move of the oracle's posteriors between float32 and float64 (same operation order), and
+      * 5x their largest relative move (float64) when the priors are perturbed by 1e-7 relative -- one float32 ulp, the size
+        of the device's transcendental-unit error per message.  Non-settling BP on a small graph full of short cycles
+        amplifies such a perturbation 2-3x per iteration: measured 3000x over 10 iterations on a 22 x 23 graph of density
+        0.33 (found by a 15 000-example soak in round 4: device -0.69961, both oracles -0.70047, all three kernel families
+        bit-identical to each other; the float32-vs-float64 move of that very entry happened to be 3e-7, the perturbation's
+        3e-4)."""
     tol, ref64 = 2e-4, None
     if method == "product_sum":
         with np.errstate(divide="ignore", invalid="ignore"):
@@ -35,9 +42,18 @@ def _own_sensitivity(oracle, g, probs, x, kind, max_iter, method, early, ref):
                                            early_exit=early)
             same = ref64["iters"] == ref["iters"]
             own = np.abs(ref64["llr"][same] - ref["llr"][same]) / (1.0 + np.abs(ref["llr"][same]))
-        own = own[np.isfinite(own)]
-        if own.size:
-            tol = max(tol, 20.0 * float(own.max()))
+            own = own[np.isfinite(own)]
+            if own.size:
+                tol = max(tol, 20.0 * float(own.max()))
+            prng = np.random.RandomState(12345)
+            for _ in range(2):
+                pert = oracle.bp_decode_batch(g, probs * (1.0 + 1e-7 * prng.randn(len(probs))), x, kind, max_iter,
+                                              ORACLE_METHOD[method], dtype="f64", threads=8, early_exit=early)
+                ok = pert["iters"] == ref64["iters"]
+                mv = np.abs(pert["llr"][ok] - ref64["llr"][ok]) / (1.0 + np.abs(ref64["llr"][ok]))
+                mv = mv[np.isfinite(mv)]
+                if mv.size:
+                    tol = max(tol, 5.0 * float(mv.max()))
     return tol, ref64
 
 
