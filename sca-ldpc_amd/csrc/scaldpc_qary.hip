@@ -939,20 +939,12 @@ __global__ void k_q_var(int v0, const int *__restrict__ col_ptr, const int *__re
 // the same order, the same first-minimum rule: identical symbols.  llr is [var][Q][Bp] here (one alphabet).
 // grid (N, Bp/64), block 64.
 //   v: variable (graph index: column of col_ptr, row of `out`);  llr: this variable's Q rows;  W: width of a message row
-//   desc: the variable's descriptor, ONE 16-byte scalar load: its (up to 4) edges in ascending check order, bit 31 = "h < 0",
-//         0x7fffffff = no edge (round 4: col_ptr -> csc_edge -> edge_h were three dependent scalar round trips in front of the
-//         first message load of a kernel that is nothing but latency)
-constexpr int VDESC_NONE = 0x7fffffff;
 template <int Q, int DMAX>
-__device__ __forceinline__ void var_small_body(int v, const float *__restrict__ llr, const int4 *__restrict__ desc, float *msg, int W,
+__device__ __forceinline__ void var_small_body(int v, const float *__restrict__ llr, const int *__restrict__ col_ptr,
+                                               const int *__restrict__ csc_edge, const int *__restrict__ edge_h, float *msg, int W,
                                                long Bp, long b, int last, signed char *__restrict__ out)
 {
-    static_assert(DMAX <= 4, "one int4 descriptor per variable");
-    const int4 dsc = desc[v];
-    const int dw[4] = {dsc.x, dsc.y, dsc.z, dsc.w};
-    int deg = 0;
-#pragma unroll
-    for (int t = 0; t < DMAX; t++) deg += (dw[t] & 0x7fffffff) != VDESC_NONE ? 1 : 0;
+    const int c0 = col_ptr[v], deg = col_ptr[v + 1] - c0;
     float sum[Q], in[DMAX][Q];
     int ed[DMAX];
     bool rv[DMAX];
@@ -963,8 +955,8 @@ __device__ __forceinline__ void var_small_body(int v, const float *__restrict__ 
         ed[t] = 0;
         rv[t] = false;
         if (t < deg) {
-            ed[t] = dw[t] & 0x7fffffff;
-            rv[t] = dw[t] < 0;
+            ed[t] = csc_edge[c0 + t];
+            rv[t] = edge_h[ed[t]] < 0;
 #pragma unroll
             for (int q = 0; q < Q; q++) in[t][q] = msg[((size_t)ed[t] * W + q) * Bp + b];
         }
@@ -1005,20 +997,22 @@ __device__ __forceinline__ void var_small_body(int v, const float *__restrict__ 
 }
 
 template <int Q, int DMAX>
-__global__ __launch_bounds__(64) void k_q_var_small(const int4 *__restrict__ desc, const float *__restrict__ llr, float *msg,
+__global__ __launch_bounds__(64) void k_q_var_small(const int *__restrict__ col_ptr, const int *__restrict__ csc_edge,
+                                                    const int *__restrict__ edge_h, const float *__restrict__ llr, float *msg,
                                                     long Bp, int batch, int last, signed char *__restrict__ out)
 {
     const int v = blockIdx.x;
     const long b = (long)blockIdx.y * 64 + threadIdx.x;
     if (b >= batch) return;
-    var_small_body<Q, DMAX>(v, llr + (size_t)v * Q * Bp, desc, msg, Q, Bp, b, last, out);
+    var_small_body<Q, DMAX>(v, llr + (size_t)v * Q * Bp, col_ptr, csc_edge, edge_h, msg, Q, Bp, b, last, out);
 }
 
 // DecoderSpecial (decoder_special.rs:566-609): the first BV variables over QA symbols (columns of at most DA checks), the
 // row-sum variables behind them over QS symbols, one check each; message rows are W = max(QA, QS) wide.
 // grid (N, Bp/64), block 64.
 template <int QA, int DA, int QS>
-__global__ __launch_bounds__(64) void k_q_var_small_special(const int4 *__restrict__ desc, const float *__restrict__ llr,
+__global__ __launch_bounds__(64) void k_q_var_small_special(const int *__restrict__ col_ptr, const int *__restrict__ csc_edge,
+                                                            const int *__restrict__ edge_h, const float *__restrict__ llr,
                                                             float *msg, int BV, int W, long Bp, int batch, int last,
                                                             signed char *__restrict__ out)
 {
@@ -1026,9 +1020,9 @@ __global__ __launch_bounds__(64) void k_q_var_small_special(const int4 *__restri
     const long b = (long)blockIdx.y * 64 + threadIdx.x;
     if (b >= batch) return;
     if (v < BV)
-        var_small_body<QA, DA>(v, llr + (size_t)v * QA * Bp, desc, msg, W, Bp, b, last, out);
+        var_small_body<QA, DA>(v, llr + (size_t)v * QA * Bp, col_ptr, csc_edge, edge_h, msg, W, Bp, b, last, out);
     else
-        var_small_body<QS, 1>(v, llr + ((size_t)BV * QA + (size_t)(v - BV) * QS) * Bp, desc, msg, W, Bp, b, last, out);
+        var_small_body<QS, 1>(v, llr + ((size_t)BV * QA + (size_t)(v - BV) * QS) * Bp, col_ptr, csc_edge, edge_h, msg, W, Bp, b, last, out);
 }
 
 // [N][Bp] -> [batch][N]
@@ -1047,7 +1041,7 @@ struct scaldpc_qary {
     int E = 0, maxdc = 0, mindc = 0, maxdv = 0;
     long llr_rows = 0;  // total alphabet rows over all variables
     int *d_row_ptr = nullptr, *d_col_ptr = nullptr, *d_csc_edge = nullptr, *d_edge_var = nullptr, *d_edge_h = nullptr,
-        *d_var_q = nullptr, *d_var_desc = nullptr;  // d_var_desc: 4 ints per variable (columns of at most 4 checks), see var_small_body
+        *d_var_q = nullptr;
     long *d_var_off = nullptr;
     std::vector<int> h_var_q;
     std::vector<long> h_var_off;
@@ -1162,15 +1156,6 @@ int qary_build(int R, int N, int B, int BSUM, bool special, const int8_t *H, int
     if (!rc) rc = up(&h->d_edge_var, edge_var.data(), E);
     if (!rc) rc = up(&h->d_edge_h, edge_h.data(), E);
     if (!rc) rc = up(&h->d_var_q, h->h_var_q.data(), N);
-    if (!rc && h->maxdv <= 4) {
-        std::vector<int> vdesc((size_t)4 * N, VDESC_NONE);
-        for (int v = 0; v < N; v++)
-            for (int t = 0; t < col_cnt[v]; t++) {
-                const int e = csc_edge[col_ptr[v] + t];
-                vdesc[(size_t)4 * v + t] = e | (edge_h[e] < 0 ? (int)0x80000000u : 0);
-            }
-        rc = up(&h->d_var_desc, vdesc.data(), vdesc.size());
-    }
     if (!rc) rc = dev_alloc(&h->d_var_off, (size_t)N);
     if (!rc && hipMemcpy(h->d_var_off, h->h_var_off.data(), sizeof(long) * N, hipMemcpyHostToDevice) != hipSuccess)
         rc = fail(SCALDPC_EHIP, "hipMemcpy failed");
@@ -1343,7 +1328,7 @@ int qary_run(scaldpc_qary *h, const float *pmf_b, const float *pmf_s, int batch,
         }
         if (timing) SC_HIP(hipEventRecord(h->tev[2 * (it - 1) + 1], s));
 #define QVAR_SMALL(QQ)                                                                                              \
-    hipLaunchKernelGGL((k_q_var_small<QQ, 4>), dim3(h->N, Bp / 64), dim3(64), 0, s, (const int4 *)h->d_var_desc, \
+    hipLaunchKernelGGL((k_q_var_small<QQ, 4>), dim3(h->N, Bp / 64), dim3(64), 0, s, h->d_col_ptr, h->d_csc_edge, h->d_edge_h, \
                        h->d_llr, h->d_msg, Bp, batch, it == iters ? 1 : 0, h->d_hard)
         const bool vs = !h->special && h->kn_var_small && h->maxdv <= 4;
         if (vs && h->Q == 3)
@@ -1355,8 +1340,8 @@ int qary_run(scaldpc_qary *h, const float *pmf_b, const float *pmf_s, int batch,
         else if (vs && h->Q == 15)  // (B = 7: the reference's criterion and unit-test decoders)
             QVAR_SMALL(15);
         else if (h->special && h->kn_var_small && h->Q == 5 && h->QS == 25 && h->maxdv <= 4)  // the Kyber SW6 classes (lib.rs:54-75)
-            hipLaunchKernelGGL((k_q_var_small_special<5, 4, 25>), dim3(h->N, Bp / 64), dim3(64), 0, s, (const int4 *)h->d_var_desc,
-                               h->d_llr, h->d_msg, BV, h->W, Bp, batch, it == iters ? 1 : 0, h->d_hard);
+            hipLaunchKernelGGL((k_q_var_small_special<5, 4, 25>), dim3(h->N, Bp / 64), dim3(64), 0, s, h->d_col_ptr, h->d_csc_edge,
+                               h->d_edge_h, h->d_llr, h->d_msg, BV, h->W, Bp, batch, it == iters ? 1 : 0, h->d_hard);
         else
             hipLaunchKernelGGL(k_q_var, dim3(h->N, Bp / TB), dim3(TB), (size_t)2 * h->W * TB * 4, s, 0, h->d_col_ptr,
                                h->d_csc_edge, h->d_edge_h, h->d_var_q, h->d_var_off, h->d_llr, h->d_msg, h->W, Bp, batch, h->W,
@@ -1521,7 +1506,7 @@ void scaldpc_qary_destroy(scaldpc_qary *h)
     DeviceGuard dg(h->device);
     dev_free(h->d_first_bad);
     dev_free(h->d_row_ptr); dev_free(h->d_col_ptr); dev_free(h->d_csc_edge); dev_free(h->d_edge_var);
-    dev_free(h->d_edge_h); dev_free(h->d_var_q); dev_free(h->d_var_desc); dev_free(h->d_var_off); dev_free(h->d_msg); dev_free(h->d_llr);
+    dev_free(h->d_edge_h); dev_free(h->d_var_q); dev_free(h->d_var_off); dev_free(h->d_msg); dev_free(h->d_llr);
     dev_free(h->d_pmf); dev_free(h->d_pmf2); dev_free(h->d_hard); dev_free(h->d_out); dev_free(h->d_err);
     for (auto &e : h->tev) (void)hipEventDestroy(e);
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
