@@ -193,6 +193,29 @@ def main():
         per_rank_ms = coll.gather_scalars(dt / args.steps * 1e3)
         dt = max(per_rank_ms) * args.steps / 1e3
 
+    # per-kernel launch durations, HIP events on the launch stream -- taken right behind the timed region, on the very
+    # state it left (before the HBM-streaming pass re-sizes the handle's arrays), and held to the driver-timed step: the
+    # pairs of a step cannot take longer than the step.  A measurement that says otherwise (seen once: a variable pass at
+    # 58 us beside a 61.6 ms step that only fits 42 us) is repeated, up to three times; the attempt with the shortest pair
+    # is the one reported, `pair.attempts_us` keeps them all.
+    def pair_ms(k):
+        return k["ms_check"] / max(1, k["launches_check"]) + k["ms_var"] / max(1, k["launches_var"])
+
+    kt, attempts = None, []
+    for _ in range(3):
+        k = dec.time_kernels(50, stream=stream)
+        attempts.append(pair_ms(k) * 1e3)
+        if kt is None or pair_ms(k) < pair_ms(kt):
+            kt = k
+        groups = -(-batch // max(1, k["codewords"] * k["lanes"]))
+        if pair_ms(kt) * groups * (iters - 1) <= 1.02 * dt / args.steps * 1e3:
+            break
+    iso = None
+    if kt["lanes"] == 2:  # the same kernels alone on the chip, one series after the other over the whole tile group
+        dec.configure(split=1)
+        iso = dec.time_kernels(50, stream=stream)
+        dec.configure(split=2)
+
     # the same kernels streaming from HBM: one tile group = the whole batch (far beyond the 256 MiB
     # Infinity Cache), same launches otherwise -- the other regime next to the cache-resident one
     hbm_stream = None
@@ -209,20 +232,11 @@ def main():
         hbm_stream = {"GBps": 16.0 * E * iters * batch / ht / 1e9, "ms_per_step": ht * 1e3,
                       "group_MB": 4.0 * E * 64 * T / 1e6}
         dec.set_tile_group(args.tile_group)
-        step()  # leave the default schedule's state behind for the kernel timing below
-        fence()
 
-    # per-kernel launch durations, HIP events on the launch stream
-    kt = dec.time_kernels(50, stream=stream)
     ms_check = kt["ms_check"] / max(1, kt["launches_check"])
     ms_var_pass = kt["ms_var"] / max(1, kt["launches_var"])
     swept = kt["codewords"]  # codewords per check launch (tile padded)
     lanes = kt["lanes"]  # 2: timed in the decode's own two-stream launch pattern (one event per launch)
-    iso = None
-    if lanes == 2:  # the same kernels alone on the chip, one series after the other over the whole tile group
-        dec.configure(split=1)
-        iso = dec.time_kernels(50, stream=stream)
-        dec.configure(split=2)
 
     # measured device copy ceiling on this very GPU (SURVEY.md 8d asks for it next to the
     # datasheet peak): 1 GiB float copy, read + write bytes / time
@@ -340,7 +354,9 @@ def main():
             "traffic": bytes_var if dom_is_var else bytes_check,
             "traffic_source": bytes_src,
             "pair": {"lanes": lanes, "us": pair_s * 1e6, "bytes_per_pair_and_lane": bytes_check + bytes_var,
-                     "bytes": {cname: bytes_check, vname: bytes_var}},
+                     "bytes": {cname: bytes_check, vname: bytes_var}, "attempts_us": attempts,
+                     # the step's own pairs: (ms_per_step - everything else) / pairs per step cannot be shorter than this
+                     "consistent_with_step": bool(pair_s * 1e3 * (-(-batch // max(1, swept * lanes))) * (iters - 1) <= 1.02 * dt / args.steps * 1e3)},
             "algorithmic_GBps": algorithmic,
             "algorithmic_frac": algorithmic / HBM_PEAK_GBS,
             "algorithmic_bytes_per_launch": 8.0 * E * (kt["codewords_var"] if dom_is_var else swept),
