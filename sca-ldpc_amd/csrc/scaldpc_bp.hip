@@ -1017,8 +1017,13 @@ struct PollState {
     int hint = 1, streak = 0, since_poll = 0;
 };
 
+// chain: bit 0 = this group CONTINUES the lanes of the group before it (same geometry, fixed iterations): no fork -- a lane's
+//        work on the new group is ordered behind its own work on the previous one by its stream, and nothing else feeds it;
+//        bit 1 = the group after this one will continue them: no join at the end.  Without the per-group join / fork the lane
+//        that runs a kernel ahead flows straight into the next group instead of idling for the other lane's last pass (and
+//        the other lane for its first): ~75 us per group of 3.7 ms on the HQC-128 bench.
 int iterate_tiles(scaldpc_bp *h, const TileState &st, int g0, int g, int max_iter, int method, float alpha, bool early,
-                  int defer_after, hipStream_t s, bool *deferred, int real_codewords, PollState *ps)
+                  int defer_after, hipStream_t s, bool *deferred, int real_codewords, PollState *ps, int chain = 0)
 {
     int *const poll_hint = ps ? &ps->hint : nullptr;
     const int poll_every = 4;
@@ -1044,7 +1049,7 @@ int iterate_tiles(scaldpc_bp *h, const TileState &st, int g0, int g, int max_ite
     if (early) SC_TRY(next_remaining_row(h, s, &rem));
     // (the accumulators / block counters of k_parity_fin and fused_commit are zeroed once per level, in decode_level,
     // and every launch leaves them zero)
-    if (nl > 1) {  // fork: the other lanes start after everything enqueued on `s` so far
+    if (nl > 1 && !(chain & 1)) {  // fork: the other lanes start after everything enqueued on `s` so far
         SC_HIP(hipEventRecord(h->ev_join[0], s));
         for (int k = 1; k < nl; k++) SC_HIP(hipStreamWaitEvent(lane[k], h->ev_join[0], 0));
     }
@@ -1141,17 +1146,18 @@ int iterate_tiles(scaldpc_bp *h, const TileState &st, int g0, int g, int max_ite
             if (ps && it >= defer_after) ps->streak = 0;
         }
     }
+    if (chain & 2) return 0;  // (the next group continues these lanes; the last one of the chain joins)
     return join();
 }
 
 // el > 0: the group is ONE tile holding `el` codewords, decoded by the row-parallel kernels.
 int iterate_group(scaldpc_bp *h, const TileState &st, int g0, int g, int max_iter, int method, float alpha, bool early,
                   int defer_after, hipStream_t s, bool *deferred, int el = 0, int real_codewords = 0,
-                  PollState *poll_hint = nullptr)
+                  PollState *poll_hint = nullptr, int chain = 0)
 {
     *deferred = false;
     if (!el)
-        return iterate_tiles(h, st, g0, g, max_iter, method, alpha, early, defer_after, s, deferred, real_codewords, poll_hint);
+        return iterate_tiles(h, st, g0, g, max_iter, method, alpha, early, defer_after, s, deferred, real_codewords, poll_hint, chain);
     const int skip = early ? 1 : 0;
     const u64 *synd_g = st.synd + (size_t)g0 * h->m;
     u64 *hard_g = st.hard + (size_t)g0 * h->n;
@@ -1225,11 +1231,21 @@ int decode_level(scaldpc_bp *h, int lvl, const TileState &st, int batch, int T, 
     std::vector<char> deferred_tile(T, 0);
     bool any = false;
     PollState poll_hint;
+    // fixed-iteration runs chain consecutive groups of the same geometry lane by lane (iterate_tiles): no host interaction,
+    // every pass of a lane depends only on that lane's previous pass over the same slice of the message array
+    // (A/B on the HQC-128 bench, best of five runs each: 60.43 against 61.12 ms per step; tanh rule 94.5 against 95.0-95.4:
+    // profiles/r04/ab_chain_groups.log)
+    const bool chainable = !early && !el && fused_init(h, method) && fixed_lanes(h, Gl) > 1;
     for (int g0 = 0; g0 < T; g0 += Gl) {
         const int g = std::min(Gl, T - g0);
         const int real = std::min(batch - g0 * TW, g * TW);
         bool d = false;
-        SC_TRY(iterate_group(h, st, g0, g, max_iter, method, alpha, early, defer_after, s, &d, el, real, &poll_hint));
+        int chain = 0;
+        if (chainable && g == Gl) {
+            if (g0 > 0) chain |= 1;                                   // (the group before it was a full one too)
+            if (g0 + Gl < T && std::min(Gl, T - (g0 + Gl)) == Gl) chain |= 2;  // ... and so is the next
+        }
+        SC_TRY(iterate_group(h, st, g0, g, max_iter, method, alpha, early, defer_after, s, &d, el, real, &poll_hint, chain));
         if (d) {
             any = true;
             for (int t = g0; t < g0 + g; t++) deferred_tile[t] = 1;
