@@ -1120,6 +1120,7 @@ int iterate_tiles(scaldpc_bp *h, const TileState &st, int g0, int g, int max_ite
             ps->since_poll < 15) {
             ps->since_poll++;  // stop here unseen, as the last groups did
             *deferred = true;
+            if (chain & 2) return 0;  // (the next group stops unseen too and continues these lanes: no host in between)
             return join();
         }
         if (early && !last && poll) {
@@ -1235,16 +1236,34 @@ int decode_level(scaldpc_bp *h, int lvl, const TileState &st, int batch, int T, 
     // every pass of a lane depends only on that lane's previous pass over the same slice of the message array
     // (A/B on the HQC-128 bench, best of five runs each: 60.43 against 61.12 ms per step; tanh rule 94.5 against 95.0-95.4:
     // profiles/r04/ab_chain_groups.log)
-    const bool chainable = !early && !el && fused_init(h, method) && fixed_lanes(h, Gl) > 1;
+    const bool lanes2 = !el && fused_init(h, method) && fixed_lanes(h, Gl) > 1;
+    const bool chainable = !early && lanes2;
+    // Early-exit runs chain too where the host stays out: a group that will stop at the hand-over point UNSEEN (two groups in
+    // a row handed a small remainder over there, the real poll of every 16th group is not due, and no earlier poll point is
+    // live) enqueues its launches without ever synchronising -- iterate_tiles decides exactly this from the PollState it is
+    // handed, so it can be foretold here.
+    auto unseen = [&](const PollState &p) {
+        return early && lanes2 && defer_after > 0 && 2 * defer_after < max_iter && p.streak >= 2 && p.since_poll < 15 && p.hint > 1 &&
+               p.hint <= defer_after;
+    };
+    bool open = false;  // the previous group left its lanes un-joined
     for (int g0 = 0; g0 < T; g0 += Gl) {
         const int g = std::min(Gl, T - g0);
         const int real = std::min(batch - g0 * TW, g * TW);
         bool d = false;
         int chain = 0;
+        const bool next_full = g0 + Gl < T && std::min(Gl, T - (g0 + Gl)) == Gl;
         if (chainable && g == Gl) {
-            if (g0 > 0) chain |= 1;                                   // (the group before it was a full one too)
-            if (g0 + Gl < T && std::min(Gl, T - (g0 + Gl)) == Gl) chain |= 2;  // ... and so is the next
+            if (g0 > 0) chain |= 1;       // (the group before it was a full one too)
+            if (next_full) chain |= 2;    // ... and so is the next
+        } else if (g == Gl && unseen(poll_hint)) {
+            PollState nxt = poll_hint;
+            nxt.since_poll++;
+            if (open) chain |= 1;
+            // (the next group takes the next row of "still running" counters: no chaining across the wrap, which clears them all)
+            if (next_full && unseen(nxt) && h->rem_slot + 2 < h->rem_rows) chain |= 2;
         }
+        open = (chain & 2) != 0;
         SC_TRY(iterate_group(h, st, g0, g, max_iter, method, alpha, early, defer_after, s, &d, el, real, &poll_hint, chain));
         if (d) {
             any = true;
