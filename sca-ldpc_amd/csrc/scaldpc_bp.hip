@@ -1013,6 +1013,7 @@ int ensure_lanes(scaldpc_bp *h, int nl)
 //          done masks afterwards, as always), with a real poll every 16th group to keep the assumption honest.
 //          A group stopped on a wrong guess only sends more codewords to the compact pass, which decodes
 //          them from their inputs: results cannot change.
+constexpr int SPEC_PERIOD = 16;  // (64 and 4096 measured the same to 0.5 % on the config-5 sweep: the polls are not where its time goes)
 struct PollState {
     int hint = 1, streak = 0, since_poll = 0;
 };
@@ -1069,7 +1070,9 @@ int iterate_tiles(scaldpc_bp *h, const TileState &st, int g0, int g, int max_ite
     // sweep, profiles/r03/ab_test_overlap.log; so was the two-launch k_parity + k_finalize form in this loop.)
     const bool ride = early && h->kn.fuse_test && check_can_test(h, method) && pw >= FT_WORDS;
     bool verdict_pending[MAX_LANES] = {};  // lane k's last variable pass has not been tested yet: its next check pass will
-    bool set_phase = true;  // (re-)establish the one-kernel offset between neighbouring lanes
+    // (re-)establish the one-kernel offset between neighbouring lanes -- in a chained group too: carrying the offset over
+    // instead measured +0.5 % on the config-5 sweep and -2 % on the fixed-iteration bench, profiles/r04/ab_chain_unseen_groups.log
+    bool set_phase = true;
     for (int it = 1; it <= max_iter; it++) {
         const bool last = it == max_iter;
         const bool no_check = first_fuse && it == 1;
@@ -1117,7 +1120,7 @@ int iterate_tiles(scaldpc_bp *h, const TileState &st, int g0, int g, int max_ite
         // a poll drains the queue (the GPU idles while the host turns around): skip the poll
         // points at which the call's earlier groups saw no codeword finish yet (`poll`, above)
         if (early && !last && poll && ps && it == defer_after && defer_after > 0 && 2 * it < max_iter && ps->streak >= 2 &&
-            ps->since_poll < 15) {
+            ps->since_poll < SPEC_PERIOD - 1) {
             ps->since_poll++;  // stop here unseen, as the last groups did
             *deferred = true;
             if (chain & 2) return 0;  // (the next group stops unseen too and continues these lanes: no host in between)
@@ -1243,7 +1246,7 @@ int decode_level(scaldpc_bp *h, int lvl, const TileState &st, int batch, int T, 
     // live) enqueues its launches without ever synchronising -- iterate_tiles decides exactly this from the PollState it is
     // handed, so it can be foretold here.
     auto unseen = [&](const PollState &p) {
-        return early && lanes2 && defer_after > 0 && 2 * defer_after < max_iter && p.streak >= 2 && p.since_poll < 15 && p.hint > 1 &&
+        return early && lanes2 && defer_after > 0 && 2 * defer_after < max_iter && p.streak >= 2 && p.since_poll < SPEC_PERIOD - 1 && p.hint > 1 &&
                p.hint <= defer_after;
     };
     bool open = false;  // the previous group left its lanes un-joined
