@@ -281,7 +281,11 @@ int scaldpc_qary_into_llr(const float *pmf, int64_t rows, int32_t Q, uint32_t fl
  * once at creation): "wave" = -1 auto | 0 codeword per lane | 1 wave per (check, codeword);
  * "unroll" = 1 register-resident unrolled enumeration for small alphabets | 0 off;
  * "tree" = 1 tree-walk check kernel for the Kyber shape (B = 2, six coefficient edges per check) | 0 off
- * (SCALDPC_QARY_NO_TREE); "timing" = 1: bracket the launches of a call with HIP events (scaldpc_qary_last_timing). */
+ * (SCALDPC_QARY_NO_TREE); "dp" = 1 (default) the same shape's check update as a min-plus recursion over the edges in the
+ * reference's order of additions -- no enumeration, the reference's messages bit for bit (scaldpc_qary_special.h) --
+ * for calls of at least "dp_min" codewords (default 5; below, the tree walk), the row's edges split over four waves up
+ * to "dp_split" codewords (default 192) | 0 off; "llr_tiled", "var_small": forms of the conversion / variable kernels;
+ * "timing" = 1: bracket the launches of a call with HIP events (scaldpc_qary_last_timing). */
 int scaldpc_qary_configure(scaldpc_qary *h, const char *key, const char *value);
 /* Measurement aid for bench.py (the q-ary counterpart of scaldpc_bp_time_kernels): after
  * scaldpc_qary_configure(h, "timing", "1"), every check-node and variable-node launch of a call is bracketed by
@@ -290,7 +294,7 @@ int scaldpc_qary_configure(scaldpc_qary *h, const char *key, const char *value);
  *                  variable launch (the iteration loop, without the probability -> LLR conversion and the copies)
  *   info[0] iterations run;  info[1] check kernel: 0 k_q_check_unrolled<3,7>, 1 k_q_check_unrolled<5,5>,
  *           2 k_q_special_check_tree<5,6> (+ wave kernel for other row degrees), 3 k_q_special_check_wave,
- *           4 k_q_check_wave, 5 k_q_special_check, 6 k_q_check;  info[2] batch;  info[3] largest check degree */
+ *           4 k_q_check_wave, 5 k_q_special_check, 6 k_q_check, 7 k_q_special_check_dp<5,6> (either form);  info[2] batch;  info[3] largest check degree */
 int scaldpc_qary_last_timing(scaldpc_qary *h, float *ms, int32_t *info);
 
 /* DecoderSpecial: H = [H' | I_R]; first N-R variables over [-B,B], last R over [-BSUM,BSUM]. */

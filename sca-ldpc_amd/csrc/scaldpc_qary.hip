@@ -33,35 +33,13 @@
 
 using namespace scaldpc;
 typedef unsigned long long u64;
+#include "scaldpc_qary_special.h"
 
 namespace {
 
 constexpr int QERR_NO_FINITE = 5;  // decoder.rs:368-375 would spin forever
 constexpr int QERR_NO_CONFIG = 6;  // decoder.rs:618 assert
 constexpr int QERR_PMF = 3;        // decoder.rs:683-684 assert
-
-__device__ __forceinline__ bool finite_f(float x) { return fabsf(x) < INFINITY; }  // false for inf and NaN
-
-// f32::min / fminf (a NaN operand is ignored) as ONE instruction.  The compiler's lowering of fminf puts a
-// canonicalising `v_max_f32 x, x, x` in front of `v_min_f32` for every operand it cannot prove quiet (sNaN
-// must come out quiet under IEEE rules): 115 extra instructions per 25 assignments in the enumeration kernels,
-// a quarter of their VALU work.  v_min_f32 itself already returns the other operand when one is a quiet NaN
-// (the only NaNs arithmetic produces here: inf - inf), which is all f32::min asks for.
-__device__ __forceinline__ float vmin(float a, float b)
-{
-    float r;
-    asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-    return r;
-}
-
-// min of three in ONE instruction (v_min3_f32 = v_min_f32 of v_min_f32: a quiet NaN operand is ignored, as in vmin)
-__device__ __forceinline__ float vmin3(float a, float b, float c)
-{
-    float r;
-    asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
-    return r;
-}
-
 
 // decoder.rs:668-692 on the device: llr[q] = ln(max_p / p[q]) in f32, with glibc's logf restated
 // for the device (scaldpc_logf.h) and the correctly rounded f32 division, so the LLRs are bit for bit
@@ -280,67 +258,6 @@ __global__ void k_q_check(const int *__restrict__ row_ptr, float *msg, int Q, in
             msg[((size_t)(e0 + j) * Q + q) * Bp + b] = Bt[(size_t)(j * Q + q) * T + tid];
 }
 
-// Check-node update of DecoderSpecial (decoder_special.rs:506-563): the first k-1 edges
-// are B-variables (alphabet QB), the last is the row-sum variable (alphabet QS); ALL
-// (2B+1)^(k-1) assignments are visited (SimpleDValueIterator, :226-275), no finiteness
-// filter; f32::min semantics (NaN ignored) = fminf.
-// LDS: Ab[nbm*QB][T], As[QS][T], Bb[nbm*QB][T], Bs[QS][T].
-__global__ void k_q_special_check(const int *__restrict__ row_ptr, float *msg, int B, int BSUM, int W, long Bp,
-                                  int batch, int nbm)
-{
-    extern __shared__ unsigned char smem[];
-    const int T = blockDim.x, tid = threadIdx.x;
-    const int QB = 2 * B + 1, QS = 2 * BSUM + 1;
-    float *Ab = (float *)smem;
-    float *As = Ab + (size_t)nbm * QB * T;
-    float *Bb = As + (size_t)QS * T;
-    float *Bs = Bb + (size_t)nbm * QB * T;
-    const int c = blockIdx.x;
-    const long b = (long)blockIdx.y * T + tid;
-    if (b >= batch) return;
-    const int e0 = row_ptr[c], k = row_ptr[c + 1] - e0, nb = k - 1;
-    for (int j = 0; j < nb; j++)
-        for (int q = 0; q < QB; q++) {
-            Ab[(size_t)(j * QB + q) * T + tid] = msg[((size_t)(e0 + j) * W + q) * Bp + b];
-            Bb[(size_t)(j * QB + q) * T + tid] = INFINITY;
-        }
-    for (int q = 0; q < QS; q++) {
-        As[(size_t)q * T + tid] = msg[((size_t)(e0 + nb) * W + q) * Bp + b];
-        Bs[(size_t)q * T + tid] = INFINITY;
-    }
-    u64 dq = 0;  // digit j = d_j + B, 8 bits each, all start at 0 (= -B)
-    for (;;) {
-        int dsum = 0;
-        float S = 0.0f;
-        for (int j = 0; j < nb; j++) {
-            const int q = (int)(dq >> (8 * j)) & 255;
-            dsum += q - B;
-            S += Ab[(size_t)(j * QB + q) * T + tid];
-        }
-        const size_t os = (size_t)(-dsum + BSUM) * T + tid;
-        S += As[os];
-        for (int j = 0; j < nb; j++) {
-            const int q = (int)(dq >> (8 * j)) & 255;
-            const size_t o = (size_t)(j * QB + q) * T + tid;
-            Bb[o] = fminf(Bb[o], S - Ab[o]);
-        }
-        Bs[os] = fminf(Bs[os], S - As[os]);
-        int j = 0;
-        for (; j < nb; j++) {
-            const int q = (int)(dq >> (8 * j)) & 255;
-            if (q < 2 * B) {
-                dq += 1ull << (8 * j);
-                break;
-            }
-            dq &= ~(255ull << (8 * j));
-        }
-        if (j >= nb) break;
-    }
-    for (int j = 0; j < nb; j++)
-        for (int q = 0; q < QB; q++) msg[((size_t)(e0 + j) * W + q) * Bp + b] = Bb[(size_t)(j * QB + q) * T + tid];
-    for (int q = 0; q < QS; q++) msg[((size_t)(e0 + nb) * W + q) * Bp + b] = Bs[(size_t)q * T + tid];
-}
-
 // ---------------------------------------------------------------------------
 // Unrolled enumeration for small alphabets (the reference's own decoder sizes: Q = 3,
 // DC <= 7; also Q = 5, DC <= 5).  Every digit is a template argument, so alpha / beta live in
@@ -364,17 +281,6 @@ __global__ void k_q_special_check(const int *__restrict__ row_ptr, float *msg, i
 // minima per assignment.  The oracle keeps the reference's form; every q-ary parity test holds this one to it.
 // lane = codeword, thread = (check, codeword).
 // ---------------------------------------------------------------------------
-// minimum of N values, two per v_min3_f32 (min is exact and order-free)
-template <int N>
-__device__ __forceinline__ float fold_min(const float (&v)[N])
-{
-    float m = v[0];
-#pragma unroll
-    for (int i = 1; i + 1 < N; i += 2) m = vmin3(m, v[i], v[i + 1]);
-    if constexpr (N % 2 == 0) m = vmin(m, v[N - 1]);
-    return m;
-}
-
 template <int Q, int K, int J, int... D>
 struct QEnum {
     // S: the left-to-right sum of alpha over the digits D... chosen so far; returns min S over the subtree
@@ -714,166 +620,6 @@ __global__ __launch_bounds__(64) void k_q_special_check_wave(const int *__restri
     }
 }
 
-// ---------------------------------------------------------------------------
-// DecoderSpecial check update for rows of NB coefficient edges over an alphabet of QB symbols --
-// the Kyber decoders' shape (lib.rs:54-75: B = 2 => QB = 5, SW = 6 => NB = 6: 5^6 = 15 625
-// assignments per check) -- as a TREE walk with everything but the commits in registers.
-//
-// What the reference computes (decoder_special.rs:506-563), per assignment d_0..d_{NB-1}:
-//     S = ((((0 + a_0[d_0]) + a_1[d_1]) + ...) + a_{NB-1}[d_{NB-1}]) + a_s[-sum d]        f32, this order
-//     beta_j[d_j] = min(beta_j[d_j], S - a_j[d_j])  for every edge j,  beta_s[-sum d] likewise
-// i.e. NB + 1 additions, NB + 1 subtractions, NB + 1 minima = 3 (NB + 1) = 21 f32 operations per
-// assignment (328 125 per check and iteration).  min is exact and order-free; the sum is not, so the
-// assignments are ENUMERATED (no min-plus shortcut), but they need not be enumerated independently:
-//   * the partial sums of a common prefix are shared (the same additions in the same order, fewer of
-//     them): a lane owns the first NB - 3 digits (its work items) and unrolls the last three, so an
-//     assignment costs 2 additions instead of NB + 1;
-//   * the lane's own digits keep their running minima in per-lane LDS tables (dynamic indices), read and
-//     committed once per work item;
-//   * the three unrolled digits index their alpha / minima with compile-time indices: registers for the
-//     whole kernel;
-//   * the row-sum symbol of an assignment is T0 - (d_{NB-3} + d_{NB-2} + d_{NB-1}): inside a work item it
-//     moves through a window of 3 QB - 2 neighbouring symbols, which is loaded to / committed from
-//     registers once per item.
-// Round 4: MIN-MARGINALS OF S (see QEnum above): x -> fl(x - a) is monotone, so
-//     beta_j[d] = min over assignments with d_j = d of fl(S - a_j[d]) = fl( (min over them of S) - a_j[d] )   bit for bit,
-// and the walk only folds sums: the unrolled block of QB d5-values lowers the two minima that belong to ITS digits
-// (d5's, the row-sum symbol's) with each S and hands ONE folded minimum up to d4's, d3's and the lane's digits.
-// Per assignment: 2 adds + 2 mins + (2 v_min3 + 1 v_min) / QB = ~4.7 VALU operations with register operands instead of
-// the 16 of the subtract-per-candidate form (the reference's own count: 21; the generic wave kernel above: ~20 LDS
-// accesses and ~100 integer / address operations); the NB * QB + QS subtractions happen once per ROW, at the commit.
-// wave = (check, codeword); LDS: Ab[NB*QB] + As[QS] floats (shared), per-lane tables
-// Bb[NB*QB][64] and Bs[QS][64]; the partial minima of the 64 lanes are combined at the end by a
-// transposed walk over the tables (exact), so the messages are bit-identical to the other kernels'.
-// grid (R, batch), block 64.  Rows whose degree is not NB + 1 are left to k_q_special_check_wave.
-// ---------------------------------------------------------------------------
-template <int QB, int NB>
-__global__ __launch_bounds__(64) void k_q_special_check_tree(const int *__restrict__ row_ptr, float *msg, int BSUM, int W,
-                                                             long Bp)
-{
-    static_assert(NB >= 3, "needs at least three coefficient edges");
-    constexpr int B = (QB - 1) / 2, NL = NB - 3, WIN = 3 * QB - 2;
-    extern __shared__ unsigned char smem[];
-    const int lane = threadIdx.x;
-    const int QS = 2 * BSUM + 1;
-    float *Ab = (float *)smem;               // [NB][QB]
-    float *As = Ab + NB * QB;                // [QS]
-    float *Bb = As + QS;                     // [NB * QB][64]   per-lane tables of the digits (the unrolled digits' rows only at the end)
-    float *Bs = Bb + (size_t)NB * QB * 64;   // [QS][64]
-    const int c = blockIdx.x;
-    const long b = blockIdx.y;
-    const int e0 = row_ptr[c], nb = row_ptr[c + 1] - e0 - 1;
-    if (nb != NB) return;
-    for (int i = lane; i < NB * QB; i += 64) Ab[i] = msg[((size_t)(e0 + i / QB) * W + i % QB) * Bp + b];
-    for (int i = lane; i < QS; i += 64) As[i] = msg[((size_t)(e0 + NB) * W + i) * Bp + b];
-    for (int i = 0; i < NL * QB; i++) Bb[(size_t)i * 64 + lane] = INFINITY;  // (the unrolled digits' rows are written at the end)
-    for (int i = 0; i < QS; i++) Bs[(size_t)i * 64 + lane] = INFINITY;
-    __syncthreads();
-    // digits NB-3 .. NB-1 are unrolled (compile-time indices): their alphas and running minima are registers for the whole kernel
-    float A3[QB], A4[QB], A5[QB], b3[QB], b4[QB], b5[QB];
-#pragma unroll
-    for (int q = 0; q < QB; q++) {
-        A3[q] = Ab[NL * QB + q];
-        A4[q] = Ab[(NB - 2) * QB + q];
-        A5[q] = Ab[(NB - 1) * QB + q];
-        b3[q] = INFINITY;
-        b4[q] = INFINITY;
-        b5[q] = INFINITY;
-    }
-    int items = 1;
-#pragma unroll
-    for (int j = 0; j < NL; j++) items *= QB;
-    for (int t = lane; t < items; t += 64) {
-        int dg[NL > 0 ? NL : 1];
-        float ml[NL > 0 ? NL : 1];
-        float P = 0.0f, gl = INFINITY;  // gl: minimum of S over this work item (all assignments with the lane's digits)
-        int dsum = 0, tt = t;
-#pragma unroll
-        for (int j = 0; j < NL; j++) {
-            dg[j] = tt % QB;
-            tt /= QB;
-            ml[j] = Bb[(size_t)(j * QB + dg[j]) * 64 + lane];  // continue from the lane's table entry
-            P += Ab[j * QB + dg[j]];  // ((0 + a_0) + a_1) + ...
-            dsum += dg[j] - B;
-        }
-        // Row-sum symbol of (.., d3, d4, d5): BSUM - (dsum + (d3-B) + (d4-B) + (d5-B)) = T0 - (d3 + d4 + d5): over the whole
-        // work item it moves through a window of 3 QB - 2 neighbouring symbols.  Their alphas and the lane's running minima
-        // are loaded ONCE per item and committed once (round 4: the window used to be re-loaded and committed for every d3 --
-        // 29 LDS operations per 25 assignments, which bound the kernel once the arithmetic had shrunk to ~5 operations per
-        // assignment).  The minima START from the lane's table entries, so the commit is a plain store.
-        const int T0 = BSUM - dsum + 3 * B;
-        float *const ps0 = &Bs[(size_t)T0 * 64 + lane];
-        float aw[WIN], mw[WIN];
-#pragma unroll
-        for (int u = 0; u < WIN; u++) {
-            aw[u] = As[T0 - u];
-            mw[u] = ps0[-(ptrdiff_t)u * 64];
-        }
-        // Every S (built left to right, the reference's additions in the reference's order) lowers the minimum of its own d5
-        // and of its row-sum symbol; the QB sums of one d4 are folded (two per v_min3_f32) into ONE number for d4's minimum,
-        // the QB of those into one for d3's, and those into one for the lane's digits.
-#pragma unroll
-        for (int d3 = 0; d3 < QB; d3++) {
-            const float P3 = P + A3[d3];
-            float g4[QB];
-#pragma unroll
-            for (int d4 = 0; d4 < QB; d4++) {
-                const float P4 = P3 + A4[d4];
-                float Sv[QB];
-#pragma unroll
-                for (int d5 = 0; d5 < QB; d5++) {
-                    Sv[d5] = (P4 + A5[d5]) + aw[d3 + d4 + d5];
-                    b5[d5] = vmin(b5[d5], Sv[d5]);
-                    mw[d3 + d4 + d5] = vmin(mw[d3 + d4 + d5], Sv[d5]);
-                }
-                g4[d4] = fold_min(Sv);
-                b4[d4] = vmin(b4[d4], g4[d4]);
-            }
-            const float g3 = fold_min(g4);
-            b3[d3] = vmin(b3[d3], g3);
-            gl = vmin(gl, g3);
-        }
-#pragma unroll
-        for (int u = 0; u < WIN; u++) ps0[-(ptrdiff_t)u * 64] = mw[u];
-#pragma unroll
-        for (int j = 0; j < NL; j++) Bb[(size_t)(j * QB + dg[j]) * 64 + lane] = vmin(ml[j], gl);
-    }
-    // Combine the 64 lanes' partial minima of S (exact: min is order-free), subtract the slot's alpha ONCE and write c2v in
-    // place (a minimum that stayed +inf -- no assignment through the slot -- gives +inf, not inf - inf).  The tables
-    // are [slot][lane] in LDS: lane s takes slot s and walks the 64 entries of its row -- rotated by its own
-    // index, so that the lanes of a wave hit 64 different banks -- instead of a butterfly of 6 cross-lane
-    // shuffles per slot (each a dependent LDS-crossbar round trip: 480 of them per wave were half a wave's
-    // life, profiles/r02/sq_counters_kyber_tree.json).  The three unrolled digits' register minima go through
-    // the table as well (rows NB-3 .. NB-1 of Bb).  (A two-phase combine over a table without those rows -- 10.2 KB of
-    // LDS per wave instead of 14.3, 15 waves per CU instead of 11 -- was measured and is SLOWER: 1.97 -> 2.08 ms per
-    // 256-codeword call, issue stalls 26 % -> 40 % of the wave cycles; profiles/r04/qary_min_marginals.log.)
-#pragma unroll
-    for (int q = 0; q < QB; q++) {
-        Bb[(size_t)(NL * QB + q) * 64 + lane] = b3[q];
-        Bb[(size_t)((NB - 2) * QB + q) * 64 + lane] = b4[q];
-        Bb[(size_t)((NB - 1) * QB + q) * 64 + lane] = b5[q];
-    }
-    __syncthreads();
-    const int nslots = NB * QB + QS;  // Bb and Bs are contiguous: one table of nslots rows
-    for (int s = lane; s < nslots; s += 64) {
-        const float *row = Bb + (size_t)s * 64;
-        float m0 = INFINITY, m1 = INFINITY, m2 = INFINITY, m3 = INFINITY;
-#pragma unroll 4
-        for (int l = 0; l < 64; l += 4) {
-            m0 = vmin(m0, row[(l + lane) & 63]);
-            m1 = vmin(m1, row[(l + 1 + lane) & 63]);
-            m2 = vmin(m2, row[(l + 2 + lane) & 63]);
-            m3 = vmin(m3, row[(l + 3 + lane) & 63]);
-        }
-        const float mS = vmin(vmin(m0, m1), vmin(m2, m3));
-        const float v = finite_f(mS) ? mS - Ab[s] : INFINITY;  // (Ab and As are contiguous: slot s's alpha is Ab[s])
-        if (s < NB * QB)
-            msg[((size_t)(e0 + s / QB) * W + s % QB) * Bp + b] = v;
-        else
-            msg[((size_t)(e0 + NB) * W + (s - NB * QB)) * Bp + b] = v;
-    }
-}
-
 // Variable-node update (decoder.rs:634-658 / decoder_special.rs:566-609).
 // thread = (variable, codeword); LDS: sum[Qmax][T], tmp[Qmax][T].
 __global__ void k_q_var(int v0, const int *__restrict__ col_ptr, const int *__restrict__ csc_edge,
@@ -1056,6 +802,9 @@ struct scaldpc_qary {
     int kn_wave = -1;    // -1: wave-parallel enumeration for batches <= 256 and the special decoder; 0 / 1 force
     int kn_unroll = 1;   // register-resident unrolled enumeration for small alphabets
     int kn_tree = 1;     // special decoder: tree-walk check kernel for the Kyber shape (QB = 5, 6 coefficient edges)
+    int kn_dp = 1;       // special decoder, same shape: min-plus recursion instead of the enumeration (k_q_special_check_dp); batches >= kn_dp_min
+    int kn_dp_min = 5;      // (below, one wave per (check, codeword) of the tree walk is as fast or faster: profiles/r04/kyber_form_sweep.log)
+    int kn_dp_split = 192;  // up to this batch the row's edges are split over four waves (same log)
     // measurement aid (bench.py): with "timing" = 1 every check / variable launch of a call is bracketed by HIP events
     // on the launch stream; scaldpc_qary_last_timing reads the sums.  Off by default: the product path records nothing.
     int kn_llr_tiled = 1;  // probability -> LLR conversion through an LDS tile (coalesced reads); A/B knob "llr_tiled"
@@ -1276,8 +1025,11 @@ int qary_run(scaldpc_qary *h, const float *pmf_b, const float *pmf_s, int batch,
     }
     // special decoder, Kyber shape (B = 2, rows of up to 6 coefficient edges + the row-sum edge): tree-walk kernel
     const int tree_nb = (h->special && h->kn_tree && (h->kn_wave != 0) && h->Q == 5 && h->maxdc - 1 == 6 && wave_lds <= 64 * 1024) ? 6 : 0;
+    // ... and from a few codewords on, the min-plus recursion (lane = codeword) instead of any enumeration
+    const int dp_nb = (h->special && h->kn_dp && (h->kn_wave != 0) && h->Q == 5 && h->maxdc - 1 == 6 && wave_lds <= 64 * 1024 &&
+                       batch >= h->kn_dp_min) ? 6 : 0;
     // which check kernel this call runs (scaldpc_qary_last_timing's info[1])
-    const int kernel_id = !h->E ? -1 : unrolled == 3 ? 0 : unrolled == 5 ? 1 : (h->special && tree_nb) ? 2 : (wave_mode && h->special) ? 3
+    const int kernel_id = !h->E ? -1 : unrolled == 3 ? 0 : unrolled == 5 ? 1 : (h->special && dp_nb) ? 7 : (h->special && tree_nb) ? 2 : (wave_mode && h->special) ? 3
                           : wave_mode ? 4 : h->special ? 5 : 6;
     const bool timing = h->kn_timing != 0;
     if (timing) {
@@ -1300,7 +1052,17 @@ int qary_run(scaldpc_qary *h, const float *pmf_b, const float *pmf_s, int batch,
                 QUNROLLED(5, 5);
             }
 #undef QUNROLLED
-            else if (h->special && tree_nb) {
+            else if (h->special && dp_nb) {
+                if (batch <= h->kn_dp_split)  // (a few dozen codewords: four waves per (check, 64 codewords))
+                    hipLaunchKernelGGL((k_q_special_check_dp<5, 6, true>), dim3(h->R, Bp / 64), dim3(256), 0, s, h->d_row_ptr, h->d_msg,
+                                       h->BSUM, h->W, Bp, batch);
+                else
+                    hipLaunchKernelGGL((k_q_special_check_dp<5, 6, false>), dim3(h->R, Bp / 64), dim3(64), 0, s, h->d_row_ptr, h->d_msg,
+                                       h->BSUM, h->W, Bp, batch);
+                if (h->mindc - 1 != dp_nb || h->maxdc - 1 != dp_nb)
+                    hipLaunchKernelGGL(k_q_special_check_wave, dim3(h->R, batch), dim3(64), wave_lds, s, h->d_row_ptr, h->d_msg,
+                                       h->B, h->BSUM, h->W, Bp, h->maxdc - 1, dp_nb);
+            } else if (h->special && tree_nb) {
                 // the Kyber shape: tree walk for the rows of 6 coefficient edges, the generic wave kernel for any others
                 const size_t tree_lds = ((size_t)tree_nb * h->Q + h->QS + (size_t)(tree_nb * h->Q + h->QS) * 64) * 4;
                 hipLaunchKernelGGL((k_q_special_check_tree<5, 6>), dim3(h->R, batch), dim3(64), tree_lds, s, h->d_row_ptr, h->d_msg,
@@ -1460,6 +1222,12 @@ int scaldpc_qary_configure(scaldpc_qary *h, const char *key, const char *value)
         h->kn_unroll = atoi(value) != 0;
     else if (!strcmp(key, "tree"))
         h->kn_tree = atoi(value) != 0;
+    else if (!strcmp(key, "dp"))
+        h->kn_dp = atoi(value) != 0;
+    else if (!strcmp(key, "dp_min"))
+        h->kn_dp_min = std::max(1, atoi(value));
+    else if (!strcmp(key, "dp_split"))
+        h->kn_dp_split = std::max(0, atoi(value));
     else if (!strcmp(key, "timing"))
         h->kn_timing = atoi(value) != 0;
     else if (!strcmp(key, "llr_tiled"))

@@ -48,12 +48,13 @@ class _QaryBase:
         return np.ascontiguousarray(H)
 
     def configure(self, **knobs):
-        """wave = -1 (auto) / 0 / 1, unroll = 0 / 1, tree = 0 / 1, timing = 0 / 1 (include/scaldpc.h, scaldpc_qary_configure)."""
+        """wave = -1 (auto) / 0 / 1, unroll = 0 / 1, tree = 0 / 1, dp = 0 / 1, dp_min = batch from which dp applies, timing = 0 / 1
+        (include/scaldpc.h, scaldpc_qary_configure)."""
         for k, v in knobs.items():
             _lib.check(self._lib.scaldpc_qary_configure(self._h, k.encode(), str(v).encode()))
 
     CHECK_KERNELS = ("k_q_check_unrolled<3,7>", "k_q_check_unrolled<5,5>", "k_q_special_check_tree<5,6>",
-                     "k_q_special_check_wave", "k_q_check_wave", "k_q_special_check", "k_q_check")
+                     "k_q_special_check_wave", "k_q_check_wave", "k_q_special_check", "k_q_check", "k_q_special_check_dp<5,6>")
 
     def last_timing(self):
         """HIP-event times of the last call's launches (after `configure(timing=1)`; bench.py's measurement aid):

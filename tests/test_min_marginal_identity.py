@@ -59,3 +59,124 @@ def test_infinite_alpha_never_forms_inf_minus_inf():
     kernels write +inf for it -- the reference's candidates there are inf - inf = NaN, which f32::min ignores: +inf as well."""
     S = np.array([np.inf, np.inf], dtype=np.float32)
     assert reference_form(S, np.float32(np.inf)) == np.inf and min_marginal_form(S, np.float32(np.inf)) == np.inf
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The min-plus recursion of k_q_special_check_dp (csrc/scaldpc_qary_special.h): no enumeration at all.
+#     S = fl(..fl(fl(0 + a_0[d_0]) + a_1[d_1]).. + a_s[-sum d])       is a chain of monotone steps x -> fl(x + c),
+# so among the assignments that agree from some edge on and have the same digit sum before it, the one with the smallest
+# partial sum has the smallest S: the minimum of S over a class of prefixes is S continued from the class's minimal
+# partial sum.  Checked here against the reference-form enumeration (decoder_special.rs:531-554) in NumPy float32, bit for
+# bit, on small checks (2 - 4 coefficient edges, alphabets of 3 and 5) with the same adversarial values.
+# ---------------------------------------------------------------------------------------------------------------------
+def _fmin_ignoring_nan(x, axis=None):
+    """f32::min over an axis: NaN candidates ignored, +inf where there is none."""
+    y = np.where(np.isnan(x), np.float32(np.inf), x)
+    return y.min(axis=axis) if axis is not None else y.min()
+
+
+def special_check_enumerated(a, a_sum, B, BSUM):
+    """Reference form: every assignment forms S left to right; beta_j[d] = min of fl(S - a_j[d]); beta_s likewise."""
+    nb, QB = a.shape
+    with np.errstate(invalid="ignore", over="ignore"):
+        S = np.zeros((1,) * nb, dtype=np.float32)
+        dsum = np.zeros((1,) * nb, dtype=np.int64)
+        for j in range(nb):
+            shape = [1] * nb
+            shape[j] = QB
+            S = (S + a[j].reshape(shape)).astype(np.float32)
+            dsum = dsum + (np.arange(QB) - B).reshape(shape)
+        t = -dsum + BSUM
+        S = (S + a_sum[t]).astype(np.float32)
+        beta = np.empty_like(a)
+        for j in range(nb):
+            shape = [1] * nb
+            shape[j] = QB
+            cand = (S - a[j].reshape(shape)).astype(np.float32)
+            beta[j] = _fmin_ignoring_nan(np.moveaxis(cand, j, 0).reshape(QB, -1), axis=1)
+        beta_s = np.full(a_sum.shape, np.inf, dtype=np.float32)
+        cand = (S - a_sum[t]).astype(np.float32)
+        for tt in np.unique(t):
+            beta_s[tt] = _fmin_ignoring_nan(cand[t == tt])
+    return beta, beta_s
+
+
+def _minplus_step(P, ak):
+    """out[u] = min over q of fl(P[u - q] + ak[q]), NaN candidates ignored (NaN where there is nothing else, like v_min3)."""
+    QB = ak.size
+    out = np.full(P.size + QB - 1, np.nan, dtype=np.float32)
+    with np.errstate(invalid="ignore", over="ignore"):
+        for u in range(out.size):
+            c = np.array([np.float32(P[u - q] + ak[q]) for q in range(QB) if 0 <= u - q < P.size], dtype=np.float32)
+            c = c[~np.isnan(c)]
+            if c.size:
+                out[u] = c.min()
+    return out
+
+
+def special_check_minplus(a, a_sum, B, BSUM):
+    nb, QB = a.shape
+    top = BSUM + nb * B
+    WN = (QB - 1) * nb + 1
+    asw = np.array([a_sum[top - w] for w in range(WN)], dtype=np.float32)
+    beta = np.empty_like(a)
+    beta_s = np.full(a_sum.shape, np.inf, dtype=np.float32)
+    P = np.zeros(1, dtype=np.float32)
+    with np.errstate(invalid="ignore", over="ignore"):
+        for j in range(nb):
+            for d in range(QB):
+                V = (P + a[j, d]).astype(np.float32)
+                for k in range(j + 1, nb):
+                    V = _minplus_step(V, a[k])
+                c = (V + asw[d : d + V.size]).astype(np.float32)
+                c = c[~np.isnan(c)]
+                M = c.min() if c.size else np.float32(np.nan)
+                beta[j, d] = np.float32(M - a[j, d]) if np.isfinite(M) else np.float32(np.inf)
+            P = _minplus_step(P, a[j])
+        for w in range(WN):
+            M = np.float32(P[w] + asw[w])
+            beta_s[top - w] = np.float32(M - asw[w]) if np.isfinite(M) else np.float32(np.inf)
+    return beta, beta_s
+
+
+def _draw(rng, shape, kind):
+    if kind == 0:  # every addition rounds: 20 binades
+        return (-np.log(rng.rand(*shape) + 1e-7) * 2.0 ** rng.randint(-10, 10, size=shape)).astype(np.float32)
+    if kind == 1:  # ties everywhere
+        return (0.25 * rng.randint(0, 8, size=shape)).astype(np.float32)
+    if kind == 2:  # impossible symbols
+        x = (-np.log(rng.rand(*shape) + 1e-7)).astype(np.float32)
+        x[rng.rand(*shape) < 0.25] = np.inf
+        return x
+    if kind == 3:  # NaN alphas (inf - inf of the variable update) and +inf
+        x = (3.0 * rng.rand(*shape)).astype(np.float32)
+        x[rng.rand(*shape) < 0.15] = np.nan
+        x[rng.rand(*shape) < 0.15] = np.inf
+        return x
+    if kind == 4:  # zeros
+        x = rng.rand(*shape).astype(np.float32)
+        x[rng.rand(*shape) < 0.3] = 0.0
+        return x
+    x = (1e30 * rng.rand(*shape)).astype(np.float32)  # sums overflow
+    big = rng.rand(*shape) < 0.2
+    x[big] = (np.finfo(np.float32).max * (0.3 + 0.5 * rng.rand(*shape))).astype(np.float32)[big]
+    return x
+
+
+def test_minplus_recursion_equals_the_enumeration_bit_for_bit():
+    rng = np.random.RandomState(5)
+    compared = 0
+    for trial in range(360):
+        kind = trial % 6
+        B = 1 + (trial // 6) % 2
+        QB = 2 * B + 1
+        nb = 2 + (trial // 12) % 3
+        BSUM = nb * B + rng.randint(0, 3)  # (the window of reachable row-sum symbols may be narrower than the alphabet)
+        a = _draw(rng, (nb, QB), kind)
+        a_sum = _draw(rng, (2 * BSUM + 1,), kind)
+        want, want_s = special_check_enumerated(a, a_sum, B, BSUM)
+        got, got_s = special_check_minplus(a, a_sum, B, BSUM)
+        assert want.tobytes() == got.tobytes(), (kind, a, a_sum, want, got)
+        assert want_s.tobytes() == got_s.tobytes(), (kind, a, a_sum, want_s, got_s)
+        compared += want.size + want_s.size
+    assert compared > 7000

@@ -146,7 +146,7 @@ def test_registered_n1024r256sw6(oracle, golden, batch):
     """The other registered Kyber size, DecoderN1024R256SW6 (simulate_rs/src/lib.rs:54-63: 256 x 1024, check blocks 1,
     column degree 2 on the coefficient side, 1 on the row-sum side), on the H the reference's own generator makes for it
     (`make_qary_qc_parity_check_matrix(256, 6, 3, RandomState(0), 1)`, fixture qary_qc_256_6_3_s0_cb1): every kernel
-    form -- tree walk (the default for B = 2 and six coefficient edges), generic wave-parallel, codeword per lane --
+    form -- min-plus recursion (the default for B = 2 and six coefficient edges), tree walk, generic wave-parallel, codeword per lane --
     against the oracle (decoder_special.rs:471-617 restated), at batch 1 (the reference's one min_sum per call) and 70,
     and once through the drop-in module the way kyber-side code reaches it: getattr(simulate_rs, name)(H, iters)
     .min_sum(channel_output, channel_output_sum) with the row-sum pmf reversed as kyber.py:374-375 does (VERDICT r03
@@ -164,10 +164,12 @@ def test_registered_n1024r256sw6(oracle, golden, batch):
     ref = oracle.qary_special_batch(g, 2, 12, pb, ps, 3, threads=8)
     dec = qary.decoder_class("DecoderN1024R256SW6")(H, 3)
     assert (dec.N, dec.R, dec.B, dec.BSUM, dec.DC) == (1024, 256, 2, 12, 7)
-    for wave, tree in ((-1, 1), (1, 1), (1, 0), (0, 0)):  # the library's choice, tree walk, generic wave kernel, lane kernel
-        dec.configure(wave=wave, tree=tree)
+    # the library's choice, min-plus recursion (whole row per lane / row split over four waves), tree walk, generic wave kernel, lane kernel
+    for kn in (dict(), dict(dp_min=1, dp_split=0), dict(dp_min=1, dp_split=1 << 20), dict(dp=0), dict(wave=1, dp=0), dict(wave=1, tree=0, dp=0),
+               dict(wave=0, tree=0, dp=0)):
+        dec.configure(**{**dict(wave=-1, tree=1, dp=1, dp_min=5, dp_split=192), **kn})
         got = dec.min_sum_batch(pb, ps)
-        assert np.array_equal(got, ref), (wave, tree)
+        assert np.array_equal(got, ref), kn
     dec.close()
     # through the drop-in module, the PyO3 surface (pydecoder.rs:96-145)
     drop = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "sca-ldpc_amd", "dropin")
@@ -243,6 +245,7 @@ def test_wave_parallel_mode_equals_lane_mode(oracle, golden, monkeypatch):
     ps = r2.dirichlet(np.ones(25), size=(2, 512)).astype(np.float32)
     dk = qary.decoder_class("DecoderN1280R512SW6")(gk.to_dense(np.int8), 2)
     t = {}
+    dk.configure(dp=0)  # (the enumerating forms; the min-plus recursion is timed last)
     for mode in ("1", "0"):
         dk.configure(wave=mode)
         dk.min_sum_batch(pb, ps)
@@ -256,9 +259,37 @@ def test_wave_parallel_mode_equals_lane_mode(oracle, golden, monkeypatch):
     generic = dk.min_sum_batch(pb, ps)
     t["generic"] = time.perf_counter() - t0
     assert np.array_equal(generic, out["1"])
+    dk.configure(wave=-1, tree=1, dp=1, dp_min=1)
+    dk.min_sum_batch(pb, ps)
+    t0 = time.perf_counter()
+    rec = dk.min_sum_batch(pb, ps)
+    t["dp"] = time.perf_counter() - t0
+    assert np.array_equal(rec, out["1"])
     assert np.array_equal(out["1"], oracle.qary_special_batch(gk, 2, 12, pb, ps, 2, threads=8))
-    print(f"Kyber N1280R512SW6, batch 2, 2 iterations: tree kernel {t['1']*1e3:.2f} ms, generic wave kernel "
-          f"{t['generic']*1e3:.2f} ms, lane mode {t['0']*1e3:.2f} ms")
+    print(f"Kyber N1280R512SW6, batch 2, 2 iterations: min-plus recursion {t['dp']*1e3:.2f} ms, tree kernel {t['1']*1e3:.2f} ms, "
+          f"generic wave kernel {t['generic']*1e3:.2f} ms, lane mode {t['0']*1e3:.2f} ms")
+
+
+def test_special_check_kernels_equal_the_enumeration_bit_for_bit():
+    """One check pass of DecoderSpecial at the Kyber shape, MESSAGE FOR MESSAGE as bit patterns: a plain host enumeration
+    in the reference's own form (decoder_special.rs:531-554: S left to right, beta lowered with S - alpha per assignment,
+    f32::min) against the product's lane kernel (same form), tree walk (min-marginal form) and min-plus recursion
+    (`k_q_special_check_dp`, whole-row and four-wave form: no enumeration; minimal partial sums in the reference's order of additions, exact because
+    x -> fl(x + c) is monotone), the kernels included from the product's header as it stands
+    (profiles/microbench/qary_dp_equivalence.hip, built by __graft_entry__.build()).  Inputs: LLRs over 20 binades, heavy
+    ties, impossible symbols (+inf), NaN alphas, zeros, overflowing sums; 12 checks x 100 codewords x 55 messages each.
+    (The decoders' only output is the symbol decisions: the parity tests above cannot see a last-bit difference in a
+    message -- this one can.)"""
+    import subprocess
+
+    d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "microbench")
+    made = subprocess.run(["make", "-C", d, "qary_dp_equivalence"], capture_output=True, text=True)  # (no-op when up to date)
+    assert made.returncode == 0, "qary_dp_equivalence does not build against the current header:\n" + made.stdout[-2000:] + made.stderr[-4000:]
+    r = subprocess.run([os.path.join(d, "qary_dp_equivalence")], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("CASE")]
+    assert len(lines) == 6 and all(" 0 differ in lane, 0 differ in tree, 0 differ in dp, 0 differ in split dp" in ln for ln in lines), r.stdout
+    print(r.stdout)
 
 
 def test_into_llr_known_answer_on_the_device():
@@ -300,10 +331,10 @@ def test_into_llr_on_the_device_is_bit_identical_to_the_hosts_logf(oracle):
 
 @pytest.mark.parametrize("batch", [1, 5, 70])
 def test_special_tree_kernel_with_mixed_row_degrees_and_impossible_symbols(oracle, batch):
-    """The Kyber-shape kernel (`k_q_special_check_tree<5, 6>`: rows of exactly six coefficient edges) shares a
+    """The Kyber-shape kernels (`k_q_special_check_dp<5, 6>` and `k_q_special_check_tree<5, 6>`: rows of exactly six coefficient edges) share a
     decode with the generic wave kernel (rows of fewer edges): a random H = [H' | I] with rows of 3..6
     coefficients, signed entries, pmfs with impossible symbols (+inf LLRs) on both alphabets -- against the
-    oracle, and the three kernel families against each other."""
+    oracle, and the kernel families against each other."""
     rng = np.random.RandomState(100 + batch)
     R, NB, B, SW = 14, 40, 2, 6
     BSUM = SW * B
@@ -328,7 +359,8 @@ def test_special_tree_kernel_with_mixed_row_degrees_and_impossible_symbols(oracl
     with np.errstate(divide="ignore"):
         ref = oracle.qary_special_batch(g, B, BSUM, pb, ps, 3, threads=8)
         out = {}
-        for name, kn in (("tree", dict(wave=-1, tree=1)), ("generic", dict(wave=1, tree=0)), ("lane", dict(wave=0, tree=0))):
+        for name, kn in (("dp", dict(wave=-1, tree=1, dp=1, dp_min=1, dp_split=0)), ("dp split", dict(wave=-1, tree=1, dp=1, dp_min=1, dp_split=1 << 20)),
+                         ("tree", dict(wave=-1, tree=1, dp=0)), ("generic", dict(wave=1, tree=0, dp=0)), ("lane", dict(wave=0, tree=0, dp=0))):
             dec.configure(**kn)
             out[name] = dec.min_sum_batch(pb, ps)
     for name, o in out.items():

@@ -47,3 +47,46 @@ def test_random_qary_instances(oracle, R, N, dc, B, batch, iters, seed, zero_fra
             return
         got = dec.min_sum_batch(pmf)
     assert np.array_equal(got, ref)
+
+
+@settings(max_examples=int(os.environ.get("SCALDPC_PROPERTY_EXAMPLES", "20")), deadline=None, derandomize=True,
+          suppress_health_check=list(HealthCheck))
+@given(R=st.integers(2, 9), NB=st.integers(8, 30), batch=st.sampled_from([1, 3, 40, 70, 130]), iters=st.integers(1, 5),
+       seed=st.integers(0, 9999), zero_frac=st.sampled_from([0.0, 0.1, 0.3]), full=st.booleans(),
+       form=st.sampled_from(["dp", "dp split", "tree", "wave", "lane"]), var_small=st.integers(0, 1))
+def test_random_special_instances(oracle, R, NB, batch, iters, seed, zero_frac, full, form, var_small):
+    """DecoderSpecial at the Kyber alphabets (B = 2, BSUM = 12) on random H = [H' | I]: rows of six coefficient edges (the
+    min-plus recursion `k_q_special_check_dp` / the tree walk) mixed with shorter rows (generic wave kernel), signed
+    entries, pmfs with impossible symbols on both alphabets (up to 30 % of them: +inf LLRs, NaN messages after the
+    variable update), ragged batches, every check-kernel form -- symbols bit-exact with the oracle
+    (decoder_special.rs:471-617 restated)."""
+    rng = np.random.RandomState(seed)
+    B, SW = 2, 6
+    BSUM = SW * B
+    Hp = np.zeros((R, NB), dtype=np.int8)
+    for r in range(R):
+        k = 6 if (full or r % 3) else rng.randint(1, 6)
+        cols = rng.choice(NB, k, replace=False)
+        Hp[r, cols] = rng.choice([-1, 1], size=k)
+    H = np.concatenate([Hp, np.eye(R, dtype=np.int8)], axis=1)
+    g = S.TannerGraph.from_dense(H)
+    pb = rng.dirichlet(np.ones(5) * 0.7, size=(batch, NB)).astype(np.float32)
+    ps = rng.dirichlet(np.ones(2 * BSUM + 1) * 0.7, size=(batch, R)).astype(np.float32)
+    if zero_frac:
+        zb = rng.rand(batch, NB, 5) < zero_frac
+        zb[..., B] = False
+        pb[zb] = 0.0
+        pb /= pb.sum(axis=2, keepdims=True)
+        zs = rng.rand(batch, R, 2 * BSUM + 1) < zero_frac
+        zs[..., BSUM] = False
+        ps[zs] = 0.0
+        ps /= ps.sum(axis=2, keepdims=True)
+    dec = qary.decoder_class(f"DecoderN{NB + R}R{R}SW{SW}")(H, iters)
+    dec.configure(var_small=var_small, **{"dp": dict(wave=-1, tree=1, dp=1, dp_min=1, dp_split=0),
+                                          "dp split": dict(wave=-1, tree=1, dp=1, dp_min=1, dp_split=1 << 20), "tree": dict(wave=-1, tree=1, dp=0),
+                                          "wave": dict(wave=1, tree=0, dp=0), "lane": dict(wave=0, tree=0, dp=0)}[form])
+    with np.errstate(divide="ignore", invalid="ignore"):
+        ref = oracle.qary_special_batch(g, B, BSUM, pb, ps, iters, threads=8)
+        got = dec.min_sum_batch(pb, ps)
+    dec.close()
+    assert np.array_equal(got, ref), form
