@@ -98,9 +98,11 @@ __global__ void k_q_into_llr_tiled(const float *__restrict__ pmf, int nv, int Q,
     const int v0 = blockIdx.x * VT;
     const long b0 = (long)blockIdx.y * 64;
     const int nvv = min(VT, nv - v0), width = nvv * Q;  // floats per codeword in this tile (<= 32)
-    if (lane < width)
-        for (int c = w; c < 64; c += VT)
-            if (b0 + c < batch) tile[c * 33 + lane] = pmf[((size_t)(b0 + c) * nv + v0) * Q + lane];
+    // (all threads of the block over the tile's 64 x width floats: every load instruction has 64 active lanes)
+    for (int idx = threadIdx.x; idx < 64 * width; idx += blockDim.x) {
+        const int c = idx / width, l = idx - c * width;
+        if (b0 + c < batch) tile[c * 33 + l] = pmf[((size_t)(b0 + c) * nv + v0) * Q + l];
+    }
     __syncthreads();
     if (w >= nvv) return;
     const int v = v0 + w;
