@@ -294,7 +294,7 @@ int scaldpc_qary_configure(scaldpc_qary *h, const char *key, const char *value);
  *                  variable launch (the iteration loop, without the probability -> LLR conversion and the copies)
  *   info[0] iterations run;  info[1] check kernel: 0 k_q_check_unrolled<3,7>, 1 k_q_check_unrolled<5,5>,
  *           2 k_q_special_check_tree<5,6> (+ wave kernel for other row degrees), 3 k_q_special_check_wave,
- *           4 k_q_check_wave, 5 k_q_special_check, 6 k_q_check, 7 k_q_special_check_dp<5,6> (either form);  info[2] batch;  info[3] largest check degree */
+ *           4 k_q_check_wave, 5 k_q_special_check, 6 k_q_check, 7 k_q_special_check_dp<5,6> (either form), 8 k_q_check_dp<3,7>;  info[2] batch;  info[3] largest check degree */
 int scaldpc_qary_last_timing(scaldpc_qary *h, float *ms, int32_t *info);
 
 /* DecoderSpecial: H = [H' | I_R]; first N-R variables over [-B,B], last R over [-BSUM,BSUM]. */

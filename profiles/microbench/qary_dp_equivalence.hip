@@ -8,6 +8,9 @@
 // all four kernels included from the product's header as it stands.  Inputs: smooth random LLRs over 20 binades (every
 // addition rounds), heavy ties, impossible symbols (+inf), NaN alphas (the variable update's inf - inf), zeros, sums that
 // overflow to +inf.  A difference is a bug in the kernel or a hole in the monotonicity argument of the header.
+// Second part, Decoder's check update (decoder.rs:585-631) at Q = 3, rows of 1 .. 7 edges (config 4's decoder): a host
+// enumeration over the finite supports in the reference's form against k_q_check_unrolled<3,7> (min-marginal enumeration) and
+// k_q_check_dp<3,7> (clipped min-plus recursion), messages as bit patterns and the error code of the pass.
 // Run by tests/test_qary_gpu.py::test_special_check_kernels_equal_the_enumeration_bit_for_bit.
 // Build: make -C profiles/microbench qary_dp_equivalence
 #include <hip/hip_runtime.h>
@@ -21,6 +24,7 @@
 #include <vector>
 typedef unsigned long long u64;
 #include "../../sca-ldpc_amd/csrc/scaldpc_qary_special.h"
+#include "../../sca-ldpc_amd/csrc/scaldpc_qary_rows.h"
 
 #define HIPOK(x)                                                                                  \
     do {                                                                                          \
@@ -91,6 +95,55 @@ void host_check(const float *a /* [NB][QB] */, const float *as /* [QS] */, float
 }
 
 size_t at(int c, int j, int q, long b) { return ((size_t)(c * (NB + 1) + j) * W + q) * Bp + b; }
+
+// decoder.rs:585-631 for one check of k edges over Q = 3 symbols: finite supports of the first k - 1 edges enumerated, the last
+// symbol follows from sum d = 0; returns 0, QERR_NO_FINITE (an edge without a finite symbol) or QERR_NO_CONFIG
+constexpr int GQ = 3, GB = 1;
+int host_check_generic(int k, const float *a /* [k][GQ] */, float *bt)
+{
+    for (int i = 0; i < k * GQ; i++) bt[i] = INFINITY;
+    int fin[8][GQ], nfin[8];
+    bool bad = false;
+    for (int j = 0; j < k; j++) {
+        nfin[j] = 0;
+        for (int q = 0; q < GQ; q++)
+            if (std::isfinite(a[j * GQ + q])) fin[j][nfin[j]++] = q;
+        bad |= nfin[j] == 0;
+    }
+    if (bad) return QERR_NO_FINITE;
+    int idx[8] = {0, 0, 0, 0, 0, 0, 0, 0}, nconf = 0;
+    for (;;) {
+        int dsum = 0, qs[8];
+        volatile float S = 0.0f;
+        for (int j = 0; j < k - 1; j++) {
+            qs[j] = fin[j][idx[j]];
+            dsum += qs[j] - GB;
+            S = S + a[j * GQ + qs[j]];
+        }
+        const int dl = -dsum;
+        if (dl >= -GB && dl <= GB) {
+            qs[k - 1] = dl + GB;
+            S = S + a[(k - 1) * GQ + qs[k - 1]];
+            if (std::isfinite(S)) {
+                nconf++;
+                for (int j = 0; j < k; j++) {
+                    volatile float c = S - a[j * GQ + qs[j]];
+                    bt[j * GQ + qs[j]] = fminf(c, bt[j * GQ + qs[j]]);
+                }
+            }
+        }
+        int j = 0;
+        for (; j < k - 1; j++) {
+            if (idx[j] + 1 < nfin[j]) {
+                idx[j]++;
+                break;
+            }
+            idx[j] = 0;
+        }
+        if (j >= k - 1) break;
+    }
+    return nconf ? 0 : QERR_NO_CONFIG;
+}
 }  // namespace
 
 int main()
@@ -168,6 +221,83 @@ int main()
         printf("CASE %-10s %ld messages (%ld of them +inf): %ld differ in lane, %ld differ in tree, %ld differ in dp, %ld differ in split dp\n",
                names[flavour], cnt, inf_out, diff[0], diff[1], diff[2], diff[3]);
         bad_total += (int)(diff[0] + diff[1] + diff[2] + diff[3] != 0);
+    }
+    // ---- Decoder (Q = 3), rows of 1 .. 7 edges ----
+    {
+        const int degs[14] = {1, 2, 3, 4, 5, 6, 7, 7, 7, 6, 5, 4, 3, 2};
+        const int GR = 14;
+        std::vector<int> rp(GR + 1, 0);
+        for (int c = 0; c < GR; c++) rp[c + 1] = rp[c] + degs[c];
+        const int GE = rp[GR];
+        const size_t gn = (size_t)GE * GQ * Bp;
+        int *d_rp, *d_err;
+        float *d_g;
+        HIPOK(hipMalloc(&d_rp, sizeof(int) * (GR + 1)));
+        HIPOK(hipMalloc(&d_err, sizeof(int)));
+        HIPOK(hipMalloc(&d_g, sizeof(float) * gn));
+        HIPOK(hipMemcpy(d_rp, rp.data(), sizeof(int) * (GR + 1), hipMemcpyHostToDevice));
+        auto gat = [&](int e, int q, long b) { return ((size_t)e * GQ + q) * Bp + b; };
+        for (int flavour = 0; flavour < 6; flavour++) {
+            std::vector<float> in(gn, 7.0f), host, out[2];
+            for (int e = 0; e < GE; e++)
+                for (int q = 0; q < GQ; q++)
+                    for (long b = 0; b < BATCH; b++) in[gat(e, q, b)] = draw(flavour);
+            host = in;
+            int host_err = 0;
+            for (int c = 0; c < GR; c++)
+                for (long b = 0; b < BATCH; b++) {
+                    float a[8 * GQ], bt[8 * GQ];
+                    const int k = degs[c];
+                    for (int j = 0; j < k; j++)
+                        for (int q = 0; q < GQ; q++) a[j * GQ + q] = in[gat(rp[c] + j, q, b)];
+                    const int st = host_check_generic(k, a, bt);
+                    if (st > host_err) host_err = st;
+                    // (a row the reference refuses -- it asserts or would not terminate -- has no messages to compare)
+                    for (int j = 0; j < k; j++)
+                        for (int q = 0; q < GQ; q++) host[gat(rp[c] + j, q, b)] = st == QERR_NO_FINITE ? NAN : bt[j * GQ + q];
+                }
+            int errs[2] = {0, 0};
+            for (int kk = 0; kk < 2; kk++) {
+                HIPOK(hipMemcpy(d_g, in.data(), sizeof(float) * gn, hipMemcpyHostToDevice));
+                HIPOK(hipMemset(d_err, 0, sizeof(int)));
+                if (kk == 0)
+                    hipLaunchKernelGGL((k_q_check_unrolled<3, 7>), dim3(GR, Bp / 64), dim3(64), 0, 0, d_rp, d_g, Bp, BATCH, d_err);
+                else
+                    hipLaunchKernelGGL((k_q_check_dp<3, 7>), dim3(GR, Bp / 64), dim3(64), 0, 0, d_rp, d_g, Bp, BATCH, d_err);
+                HIPOK(hipGetLastError());
+                HIPOK(hipDeviceSynchronize());
+                out[kk].resize(gn);
+                HIPOK(hipMemcpy(out[kk].data(), d_g, sizeof(float) * gn, hipMemcpyDeviceToHost));
+                HIPOK(hipMemcpy(&errs[kk], d_err, sizeof(int), hipMemcpyDeviceToHost));
+            }
+            long cnt = 0, diff[2] = {0, 0}, skipped = 0;
+            for (int e = 0; e < GE; e++)
+                for (int q = 0; q < GQ; q++)
+                    for (long b = 0; b < BATCH; b++) {
+                        const size_t i = gat(e, q, b);
+                        if (std::isnan(host[i])) {
+                            skipped++;
+                            continue;
+                        }
+                        uint32_t h;
+                        memcpy(&h, &host[i], 4);
+                        cnt++;
+                        for (int kk = 0; kk < 2; kk++) {
+                            uint32_t g;
+                            memcpy(&g, &out[kk][i], 4);
+                            if (g != h && diff[kk]++ < 3)
+                                fprintf(stderr, "generic %s kernel %d: edge %d symbol %d codeword %ld: %a (host) vs %a\n", names[flavour], kk, e, q, b,
+                                        host[i], out[kk][i]);
+                        }
+                    }
+            printf("GENERIC %-10s %ld messages (%ld more in rows the reference refuses), error code %d: %ld differ in unrolled (code %d), "
+                   "%ld differ in dp (code %d)\n",
+                   names[flavour], cnt, skipped, host_err, diff[0], errs[0], diff[1], errs[1]);
+            bad_total += (int)(diff[0] + diff[1] != 0 || errs[0] != host_err || errs[1] != host_err);
+        }
+        hipFree(d_rp);
+        hipFree(d_err);
+        hipFree(d_g);
     }
     hipFree(d_row_ptr);
     hipFree(d_in);

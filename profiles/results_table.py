@@ -51,7 +51,7 @@ def main():
         rows.append(f"| `qary_config4` (config 4) | {d['value']:.3g} symbol-edge updates/s, **{d['ms_per_step']:.2f} ms** per 1024-codeword call "
                     f"({d['codewords_per_s'] / 1e6:.2f} M codewords/s; host arrays in / out {d['host_buffers']['ms_per_step']:.2f} ms) | `bound: valu`, "
                     f"`{d['roofline']['kernel']}` {d['kernel_ms']['check_per_launch'] * 1e3:.1f} µs per launch: **executed {fr:.2f}** of the VALU peak "
-                    f"({ex['instructions_per_reference_op']:.2f} lane-instructions per reference operation: min-marginal form; the reference's own "
+                    f"({ex['instructions_per_reference_op']:.2f} lane-instructions per reference operation: the min-plus recursion does not enumerate; the reference's own "
                     f"operation count over the same time would read {ro:.2f}) | C port of `decoder.rs`: {d['cpu_baseline']['value']:.2g} updates/s on "
                     f"{d['cpu_baseline']['cores']} threads, {d['cpu_baseline']['single_thread_ms_per_call']:.1f} ms per call on one core |")
     ks = [R.get(f"kyber_sw6_b{b}") for b in ("256", "64", "1")]

@@ -34,11 +34,10 @@
 using namespace scaldpc;
 typedef unsigned long long u64;
 #include "scaldpc_qary_special.h"
+#include "scaldpc_qary_rows.h"
 
 namespace {
 
-constexpr int QERR_NO_FINITE = 5;  // decoder.rs:368-375 would spin forever
-constexpr int QERR_NO_CONFIG = 6;  // decoder.rs:618 assert
 constexpr int QERR_PMF = 3;        // decoder.rs:683-684 assert
 
 // decoder.rs:668-692 on the device: llr[q] = ln(max_p / p[q]) in f32, with glibc's logf restated
@@ -260,167 +259,6 @@ __global__ void k_q_check(const int *__restrict__ row_ptr, float *msg, int Q, in
             msg[((size_t)(e0 + j) * Q + q) * Bp + b] = Bt[(size_t)(j * Q + q) * T + tid];
 }
 
-// ---------------------------------------------------------------------------
-// Unrolled enumeration for small alphabets (the reference's own decoder sizes: Q = 3,
-// DC <= 7; also Q = 5, DC <= 5).  Every digit is a template argument, so alpha / beta live in
-// registers with compile-time indices -- no LDS, no index arithmetic.  S is built left to
-// right through the recursion (the partial sum of the first j digits is shared by all
-// assignments below it: the same additions in the same order as decoder.rs:600-610, fewer of
-// them).  No finite-support filter is needed: an assignment through a non-finite alpha has
-// S = inf or NaN, and v_min never lets those lower a minimum -- exactly the assignments
-// FiniteDValueIterator / `cfg.sum.is_finite()` (decoder.rs:281-401, 612) would have skipped.
-//
-// MIN-MARGINALS OF S, ONE SUBTRACTION PER OUTPUT (round 4).  The reference computes, for every edge j and symbol d,
-//     beta_j[d] = min over the assignments with d_j = d of fl(S - alpha_j[d])          (decoder.rs:621-627)
-// with alpha_j[d] the SAME number in every candidate.  x -> fl(x - a) is monotone non-decreasing (exact subtraction is,
-// and so is rounding), so the minimum of the candidates is the candidate of the minimum:
-//     beta_j[d] = fl( M_j[d] - alpha_j[d] ),   M_j[d] = min over those assignments of S      -- bit for bit.
-// (A minimum that stays +inf -- no assignment with a finite sum through (j, d) -- gives beta = +inf without forming
-// inf - inf; a finite M implies a finite alpha_j[d], which is one of its summands.)  The enumeration therefore only
-// folds sums: every node of the digit tree returns the minimum of S over its subtree, the node for digit q of edge J
-// lowers M[J][q] with it, and the K subtractions per assignment (+ K minima) of the reference's form -- 7 x 729 each
-// for config 4's checks, 3956 v_sub and 2973 v_min per row -- become Q x K subtractions per ROW and about three
-// minima per assignment.  The oracle keeps the reference's form; every q-ary parity test holds this one to it.
-// lane = codeword, thread = (check, codeword).
-// ---------------------------------------------------------------------------
-template <int Q, int K, int J, int... D>
-struct QEnum {
-    // S: the left-to-right sum of alpha over the digits D... chosen so far; returns min S over the subtree
-    static __device__ __forceinline__ float run(const float (&A)[K][Q], float (&M)[K][Q], float S)
-    {
-        return run_q(A, M, S, std::make_integer_sequence<int, Q>());
-    }
-    template <int... Qs>
-    static __device__ __forceinline__ float run_q(const float (&A)[K][Q], float (&M)[K][Q], float S, std::integer_sequence<int, Qs...>)
-    {
-        const float sub[Q] = {QEnum<Q, K, J + 1, D..., Qs>::run(A, M, S + A[J][Qs])...};
-#pragma unroll
-        for (int q = 0; q < Q; q++) M[J][q] = vmin(M[J][q], sub[q]);
-        return fold_min(sub);
-    }
-};
-// Last FREE digit (edge K-2; edge K-1's digit then follows from sum d = 0).
-template <int Q, int K, int... D>
-struct QEnum<Q, K, K - 2, D...> {
-    static_assert(sizeof...(D) == K - 2, "digits of the edges before the last free one");
-    static constexpr int B = (Q - 1) / 2;
-    static constexpr int base = -((D - B) + ... + 0);
-    static constexpr int dl(int q) { return base - (q - B); }           // digit of the last edge when edge K-2 takes q
-    static constexpr bool ok(int q) { return dl(q) >= -B && dl(q) <= B; }
-    static constexpr int nvalid()
-    {
-        int n = 0;
-        for (int q = 0; q < Q; q++) n += ok(q) ? 1 : 0;
-        return n;
-    }
-    static constexpr int slot(int q)  // valid q -> its slot among the valid ones
-    {
-        int n = 0;
-        for (int t = 0; t < q; t++) n += ok(t) ? 1 : 0;
-        return n;
-    }
-    static __device__ __forceinline__ float run(const float (&A)[K][Q], float (&M)[K][Q], float S)
-    {
-        constexpr int NV = nvalid();
-        if constexpr (NV > 0) {
-            float S2[NV];
-            fill(A, M, S, S2, std::make_integer_sequence<int, Q>());
-            return fold_min(S2);
-        }
-        return INFINITY;
-    }
-    template <int... Qs>
-    static __device__ __forceinline__ void fill(const float (&A)[K][Q], float (&M)[K][Q], float S, float (&S2)[nvalid()], std::integer_sequence<int, Qs...>)
-    {
-        (one<Qs>(A, M, S, S2), ...);
-    }
-    template <int q>
-    static __device__ __forceinline__ void one(const float (&A)[K][Q], float (&M)[K][Q], float S, float (&S2)[nvalid()])
-    {
-        if constexpr (ok(q)) {
-            constexpr int ql = dl(q) + B;
-            const float s2 = (S + A[K - 2][q]) + A[K - 1][ql];  // the reference's additions in the reference's order
-            S2[slot(q)] = s2;
-            M[K - 2][q] = vmin(M[K - 2][q], s2);
-            M[K - 1][ql] = vmin(M[K - 1][ql], s2);
-        }
-    }
-};
-// last edge: its digit is fixed by sum d = 0 (reached directly only when K = 1)
-template <int Q, int K, int... D>
-struct QEnum<Q, K, K - 1, D...> {
-    static constexpr int B = (Q - 1) / 2;
-    static constexpr int dl = -((D - B) + ... + 0);
-    static __device__ __forceinline__ float run(const float (&A)[K][Q], float (&M)[K][Q], float S)
-    {
-        if constexpr (dl >= -B && dl <= B) {
-            constexpr int ql = dl + B;
-            const float S2 = S + A[K - 1][ql];
-            M[K - 1][ql] = vmin(M[K - 1][ql], S2);
-            return S2;
-        }
-        return INFINITY;
-    }
-};
-
-template <int Q, int K>
-__device__ __forceinline__ void q_check_unrolled(float *msg, int e0, long Bp, long b, int *err)
-{
-    float A[K][Q], M[K][Q];
-#pragma unroll
-    for (int j = 0; j < K; j++)
-#pragma unroll
-        for (int q = 0; q < Q; q++) {
-            A[j][q] = msg[((size_t)(e0 + j) * Q + q) * Bp + b];
-            M[j][q] = INFINITY;
-        }
-    QEnum<Q, K, 0>::run(A, M, 0.0f);
-    // "at least one configuration" (decoder.rs:618 asserts it): an assignment with a finite sum makes M[0][d_0] finite, and
-    // nothing else does
-    bool any_conf = false;
-#pragma unroll
-    for (int q = 0; q < Q; q++) any_conf |= finite_f(M[0][q]);
-    if (!any_conf) {
-        bool bad = false;
-#pragma unroll
-        for (int j = 0; j < K; j++) {
-            bool any = false;
-#pragma unroll
-            for (int q = 0; q < Q; q++) any |= finite_f(A[j][q]);
-            bad |= !any;
-        }
-        atomicMax(err, bad ? QERR_NO_FINITE : QERR_NO_CONFIG);
-    }
-#pragma unroll
-    for (int j = 0; j < K; j++)
-#pragma unroll
-        for (int q = 0; q < Q; q++)
-            msg[((size_t)(e0 + j) * Q + q) * Bp + b] = finite_f(M[j][q]) ? M[j][q] - A[j][q] : INFINITY;  // (see above: one subtraction per output)
-}
-
-// grid (R, Bp/64), block 64.  Registers: 97 (Q = 3, DC = 7) / 115 (Q = 5, DC = 5) since round 4 -- four waves per SIMD.
-// Until then a per-assignment configuration counter (v_cmp_class into an SGPR pair + add-with-carry for each of the 729
-// assignments) had the compiler hold hundreds of masks: 294 registers, ONE wave per SIMD (two with a forced allocation
-// and spills), and config 4's 2400 waves ran in two rounds: 48.9 -> 30.9 us per launch without it (see q_check_unrolled).
-template <int Q, int KMAX>
-__global__ __launch_bounds__(64) void k_q_check_unrolled(
-    const int *__restrict__ row_ptr, float *msg, long Bp, int batch, int *__restrict__ err)
-{
-    const int c = blockIdx.x;
-    const long b = (long)blockIdx.y * blockDim.x + threadIdx.x;
-    if (b >= batch) return;
-    const int e0 = row_ptr[c], k = row_ptr[c + 1] - e0;
-#define QK(KK)                                                              \
-    case KK:                                                                \
-        if constexpr (KK <= KMAX) q_check_unrolled<Q, KK>(msg, e0, Bp, b, err); \
-        break;
-    switch (k) {
-        QK(1) QK(2) QK(3) QK(4) QK(5) QK(6) QK(7) QK(8)
-        default:
-            if (threadIdx.x == 0) atomicMax(err, QERR_NO_CONFIG);  // k == 0 (k > KMAX never reaches this kernel)
-    }
-#undef QK
-}
 
 // ---------------------------------------------------------------------------
 // Small and medium batches (<= 256; single `min_sum` calls are the reference's usual pattern): lane = codeword
@@ -1031,7 +869,7 @@ int qary_run(scaldpc_qary *h, const float *pmf_b, const float *pmf_s, int batch,
     const int dp_nb = (h->special && h->kn_dp && (h->kn_wave != 0) && h->Q == 5 && h->maxdc - 1 == 6 && wave_lds <= 64 * 1024 &&
                        batch >= h->kn_dp_min) ? 6 : 0;
     // which check kernel this call runs (scaldpc_qary_last_timing's info[1])
-    const int kernel_id = !h->E ? -1 : unrolled == 3 ? 0 : unrolled == 5 ? 1 : (h->special && dp_nb) ? 7 : (h->special && tree_nb) ? 2 : (wave_mode && h->special) ? 3
+    const int kernel_id = !h->E ? -1 : (unrolled == 3 && h->kn_dp) ? 8 : unrolled == 3 ? 0 : unrolled == 5 ? 1 : (h->special && dp_nb) ? 7 : (h->special && tree_nb) ? 2 : (wave_mode && h->special) ? 3
                           : wave_mode ? 4 : h->special ? 5 : 6;
     const bool timing = h->kn_timing != 0;
     if (timing) {
@@ -1048,7 +886,9 @@ int qary_run(scaldpc_qary *h, const float *pmf_b, const float *pmf_s, int batch,
 #define QUNROLLED(QQ, KK)                                                                                         \
     hipLaunchKernelGGL((k_q_check_unrolled<QQ, KK>), dim3(h->R, Bp / 64), dim3(64), 0, s, h->d_row_ptr, h->d_msg, Bp, \
                        batch, h->d_err)
-            if (unrolled == 3) {
+            if (unrolled == 3 && h->kn_dp) {
+                hipLaunchKernelGGL((k_q_check_dp<3, 7>), dim3(h->R, Bp / 64), dim3(64), 0, s, h->d_row_ptr, h->d_msg, Bp, batch, h->d_err);
+            } else if (unrolled == 3) {
                 QUNROLLED(3, 7);
             } else if (unrolled == 5) {
                 QUNROLLED(5, 5);

@@ -54,7 +54,7 @@ class _QaryBase:
             _lib.check(self._lib.scaldpc_qary_configure(self._h, k.encode(), str(v).encode()))
 
     CHECK_KERNELS = ("k_q_check_unrolled<3,7>", "k_q_check_unrolled<5,5>", "k_q_special_check_tree<5,6>",
-                     "k_q_special_check_wave", "k_q_check_wave", "k_q_special_check", "k_q_check", "k_q_special_check_dp<5,6>")
+                     "k_q_special_check_wave", "k_q_check_wave", "k_q_special_check", "k_q_check", "k_q_special_check_dp<5,6>", "k_q_check_dp<3,7>")
 
     def last_timing(self):
         """HIP-event times of the last call's launches (after `configure(timing=1)`; bench.py's measurement aid):

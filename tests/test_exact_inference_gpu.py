@@ -116,7 +116,7 @@ def test_single_decode_attributes_are_the_exact_marginals():
 
 
 # ------------------------------------------------------------------------------- q-ary
-@pytest.mark.parametrize("knobs", [dict(), dict(wave=0), dict(wave=1), dict(unroll=0, wave=0), dict(unroll=0, wave=1)])
+@pytest.mark.parametrize("knobs", [dict(), dict(dp=0), dict(wave=0), dict(wave=1), dict(unroll=0, wave=0), dict(unroll=0, wave=1)])
 @pytest.mark.parametrize("B", [1, 2])
 def test_qary_min_sum_finds_the_minimum_cost_assignment(B, knobs):
     for seed in range(10):

@@ -82,9 +82,11 @@ def test_config4_vs_oracle(oracle, golden, batch):
             mask = rng.rand(450) < (0.005 if b % 3 == 0 else 0.08)
             pmf[b] = np.where(mask[:, None], bad, good)
     dec = qary.decoder_class("DecoderN450R150V3C7B1")(g.to_dense(np.int8), 5)
-    got = dec.min_sum_batch(pmf)
+    got = dec.min_sum_batch(pmf)  # (the default: clipped min-plus recursion, k_q_check_dp<3,7>)
     ref = oracle.qary_min_sum_batch(g, 3, pmf, 5, threads=8)
     assert np.array_equal(got, ref)
+    dec.configure(dp=0)  # the unrolled enumeration
+    assert np.array_equal(dec.min_sum_batch(pmf), ref)
     if batch >= 70:
         assert (got != 0).any() and (got == 0).all(axis=1).any()  # both outcomes exercised
 
@@ -289,6 +291,11 @@ def test_special_check_kernels_equal_the_enumeration_bit_for_bit():
     assert r.returncode == 0, r.stdout + r.stderr
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("CASE")]
     assert len(lines) == 6 and all(" 0 differ in lane, 0 differ in tree, 0 differ in dp, 0 differ in split dp" in ln for ln in lines), r.stdout
+    # second part: Decoder's check update at Q = 3, rows of 1 .. 7 edges (config 4's decoder) -- host enumeration over the finite
+    # supports (decoder.rs:585-631) against k_q_check_unrolled<3,7> and the clipped min-plus recursion k_q_check_dp<3,7>,
+    # messages and the error code of the pass (the program's exit code covers the codes)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("GENERIC")]
+    assert len(lines) == 6 and all(" 0 differ in unrolled" in ln and " 0 differ in dp" in ln for ln in lines), r.stdout
     print(r.stdout)
 
 

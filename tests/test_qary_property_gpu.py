@@ -15,13 +15,24 @@ from helpers import S
 pytestmark = pytest.mark.gpu
 qary = importlib.import_module("sca-ldpc_amd.qary")
 
+_examples = [0]
+
+
+def _progress():
+    """A line every 25 examples (long soak runs with SCALDPC_PROPERTY_EXAMPLES in the thousands: a GPU box takes minutes of silence for a hang)."""
+    _examples[0] += 1
+    if _examples[0] % 25 == 0:
+        print(f"[q-ary property examples: {_examples[0]}]", flush=True)
+
 
 @settings(max_examples=int(os.environ.get("SCALDPC_PROPERTY_EXAMPLES", "30")), deadline=None, derandomize=True,
           suppress_health_check=list(HealthCheck))
 @given(R=st.integers(2, 10), N=st.integers(6, 24), dc=st.integers(2, 5), B=st.integers(1, 3),
        batch=st.sampled_from([1, 3, 40, 70, 300]), iters=st.integers(1, 6), seed=st.integers(0, 9999),
-       zero_frac=st.sampled_from([0.0, 0.1]), wave=st.sampled_from([-1, 0, 1]), var_small=st.integers(0, 1), llr_tiled=st.integers(0, 1))
-def test_random_qary_instances(oracle, R, N, dc, B, batch, iters, seed, zero_frac, wave, var_small, llr_tiled):
+       zero_frac=st.sampled_from([0.0, 0.1]), wave=st.sampled_from([-1, 0, 1]), var_small=st.integers(0, 1), llr_tiled=st.integers(0, 1),
+       dp=st.integers(0, 1))
+def test_random_qary_instances(oracle, R, N, dc, B, batch, iters, seed, zero_frac, wave, var_small, llr_tiled, dp):
+    _progress()
     rng = np.random.RandomState(seed)
     Q = 2 * B + 1
     H = np.zeros((R, N), dtype=np.int8)
@@ -37,7 +48,8 @@ def test_random_qary_instances(oracle, R, N, dc, B, batch, iters, seed, zero_fra
         pmf /= pmf.sum(axis=2, keepdims=True)
     name = f"DecoderN{N}R{R}V{max(1, int(g.col_degrees().max()))}C{int(g.row_degrees().max())}B{B}"
     dec = qary.decoder_class(name)(H, iters)
-    dec.configure(wave=wave, var_small=var_small, llr_tiled=llr_tiled)  # kernel-form knobs: wave / lane mode, register-resident variable update, tiled conversion -- invisible
+    # kernel-form knobs: wave / lane mode, register-resident variable update, tiled conversion, min-plus recursion or unrolled enumeration (Q = 3) -- invisible
+    dec.configure(wave=wave, var_small=var_small, llr_tiled=llr_tiled, dp=dp)
     with np.errstate(divide="ignore"):
         try:
             ref = oracle.qary_min_sum_batch(g, Q, pmf, iters, threads=4)
@@ -60,6 +72,7 @@ def test_random_special_instances(oracle, R, NB, batch, iters, seed, zero_frac, 
     entries, pmfs with impossible symbols on both alphabets (up to 30 % of them: +inf LLRs, NaN messages after the
     variable update), ragged batches, every check-kernel form -- symbols bit-exact with the oracle
     (decoder_special.rs:471-617 restated)."""
+    _progress()
     rng = np.random.RandomState(seed)
     B, SW = 2, 6
     BSUM = SW * B
