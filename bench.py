@@ -858,7 +858,7 @@ def qary_bench(args, S, rank, world, coll, local, iters):
             # point-mass channel outputs: almost every message entry is +inf and the reference enumerates finite
             # supports only (decoder.rs:281-401) -- a handful of assignments per check, nothing like Q^(k-1).  The call
             # is LAUNCH-bound: 2 * iterations + 4 launches and two copies around microseconds of arithmetic.
-            launches = 2 * kt["iterations"] + 4
+            launches = 2 * kt["iterations"] + 3  # (status fill, conversion, the loop, unpack)
             line["roofline"] = {
                 "bound": "launch", "kernel": kt["check_kernel"], "unit": "launches/s", "achieved": launches * args.steps * world / dt,
                 "peak": None, "frac": None, "traffic": None, "launches_per_call": launches,

@@ -69,7 +69,7 @@ __global__ void k_q_into_llr(const float *__restrict__ pmf, int nv, int Q, int b
     if (!have || !(sum < 1.0f + 0.001f) || !(sum > 1.0f - 0.001f)) {
         atomicMax(err, QERR_PMF);
         // key: codeword, then alphabet (0 = coefficient rows, 1 = row-sum rows), then variable, then "no maximum"
-        atomicMin(first_bad, ((u64)b << 32) | ((u64)kind << 31) | ((u64)v << 1) | (have ? 0ull : 1ull));
+        atomicMax(first_bad, ~(((u64)b << 32) | ((u64)kind << 31) | ((u64)v << 1) | (have ? 0ull : 1ull)));  // (kept inverted: see scaldpc_qary::d_status)
     }
     // measured channel outputs repeat a handful of rows: no point caching across lanes, the double
     // pipe is idle anyway (18 double operations per symbol)
@@ -125,7 +125,7 @@ __global__ void k_q_into_llr_tiled(const float *__restrict__ pmf, int nv, int Q,
     }
     if (!have || !(sum < 1.0f + 0.001f) || !(sum > 1.0f - 0.001f)) {
         atomicMax(err, QERR_PMF);
-        atomicMin(first_bad, ((u64)b << 32) | ((u64)kind << 31) | ((u64)v << 1) | (have ? 0ull : 1ull));
+        atomicMax(first_bad, ~(((u64)b << 32) | ((u64)kind << 31) | ((u64)v << 1) | (have ? 0ull : 1ull)));  // (kept inverted: see scaldpc_qary::d_status)
     }
     float *own = tile + lane * 33 + w * Q;  // (this thread's slots of the tile: probabilities in, LLRs out)
     for (int q = 0; q < Q; q++) {
@@ -635,8 +635,12 @@ struct scaldpc_qary {
     float *d_msg = nullptr, *d_llr = nullptr, *d_pmf = nullptr, *d_pmf2 = nullptr;
     signed char *d_hard = nullptr, *d_out = nullptr;
     size_t cap_pmf = 0, cap_pmf2 = 0, cap_out = 0;
-    int *d_err = nullptr;
-    u64 *d_first_bad = nullptr;  // smallest (codeword, variable) key whose pmf row fails the sum test
+    // one 16-byte status block per handle, zeroed by ONE fill and read back by ONE copy per call: [0] = the bitwise complement of
+    // the smallest (codeword, variable) key whose pmf row fails the sum test (0: none; kept inverted so that "none" is zero
+    // and the kernels lower the key with atomicMax), [1] = the call's error code (low word)
+    u64 *d_status = nullptr;
+    int *d_err = nullptr;        // = (int *)(d_status + 1)
+    u64 *d_first_bad = nullptr;  // = d_status
     hipStream_t own_stream = nullptr;
     int device = 0;      // the device the handle was created on; every entry point runs there
     int kn_wave = -1;    // -1: wave-parallel enumeration for batches <= 256 and the special decoder; 0 / 1 force
@@ -748,8 +752,11 @@ int qary_build(int R, int N, int B, int BSUM, bool special, const int8_t *H, int
     if (!rc) rc = dev_alloc(&h->d_var_off, (size_t)N);
     if (!rc && hipMemcpy(h->d_var_off, h->h_var_off.data(), sizeof(long) * N, hipMemcpyHostToDevice) != hipSuccess)
         rc = fail(SCALDPC_EHIP, "hipMemcpy failed");
-    if (!rc) rc = dev_alloc(&h->d_err, 1);
-    if (!rc) rc = dev_alloc(&h->d_first_bad, 1);
+    if (!rc) rc = dev_alloc(&h->d_status, 2);
+    if (!rc) {
+        h->d_first_bad = h->d_status;
+        h->d_err = (int *)(h->d_status + 1);
+    }
     if (!rc && hipGetDevice(&h->device) != hipSuccess) rc = fail(SCALDPC_EHIP, "hipGetDevice failed");
     if (const char *e = getenv("SCALDPC_QARY_WAVE")) h->kn_wave = atoi(e) != 0;  // the environment is read once per handle
     if (getenv("SCALDPC_QARY_NO_UNROLL")) h->kn_unroll = 0;
@@ -794,8 +801,7 @@ int qary_run(scaldpc_qary *h, const float *pmf_b, const float *pmf_s, int batch,
         SC_TRY(dev_alloc(&h->d_hard, (size_t)h->N * Bp));
         h->cap_bp = Bp;
     }
-    SC_HIP(hipMemsetAsync(h->d_err, 0, sizeof(int), s));
-    SC_HIP(hipMemsetAsync(h->d_first_bad, 0xFF, sizeof(u64), s));
+    SC_HIP(hipMemsetAsync(h->d_status, 0, 2 * sizeof(u64), s));
     const int TB = 64;
     // probabilities -> LLRs on the device (host inputs are staged as they are: [batch][var][Q] floats)
     const float *dp_b = pmf_b, *dp_s = pmf_s;
@@ -961,12 +967,12 @@ int qary_run(scaldpc_qary *h, const float *pmf_b, const float *pmf_s, int batch,
     }
     hipLaunchKernelGGL(k_q_unpack, dim3((h->N + 255) / 256, batch), dim3(256), 0, s, h->d_hard, h->N, batch, Bp, dout);
     SC_HIP(hipGetLastError());
-    int err = 0;
-    u64 bad = ~0ull;
-    SC_HIP(hipMemcpyAsync(&err, h->d_err, sizeof(int), hipMemcpyDeviceToHost, s));
-    SC_HIP(hipMemcpyAsync(&bad, h->d_first_bad, sizeof(u64), hipMemcpyDeviceToHost, s));
+    u64 status[2] = {0, 0};
+    SC_HIP(hipMemcpyAsync(status, h->d_status, sizeof(status), hipMemcpyDeviceToHost, s));
     if (!dev_io) SC_HIP(hipMemcpyAsync(out, dout, (size_t)batch * h->N, hipMemcpyDeviceToHost, s));
     SC_HIP(hipStreamSynchronize(s));
+    const int err = (int)(unsigned)status[1];
+    const u64 bad = ~status[0];
     if (timing) {
         h->stat_ms_check = h->stat_ms_var = 0.f;
         for (int it = 0; it < iters; it++) {
@@ -1114,10 +1120,10 @@ void scaldpc_qary_destroy(scaldpc_qary *h)
 {
     if (!h) return;
     DeviceGuard dg(h->device);
-    dev_free(h->d_first_bad);
+    dev_free(h->d_status);
     dev_free(h->d_row_ptr); dev_free(h->d_col_ptr); dev_free(h->d_csc_edge); dev_free(h->d_edge_var);
     dev_free(h->d_edge_h); dev_free(h->d_var_q); dev_free(h->d_var_off); dev_free(h->d_msg); dev_free(h->d_llr);
-    dev_free(h->d_pmf); dev_free(h->d_pmf2); dev_free(h->d_hard); dev_free(h->d_out); dev_free(h->d_err);
+    dev_free(h->d_pmf); dev_free(h->d_pmf2); dev_free(h->d_hard); dev_free(h->d_out);
     for (auto &e : h->tev) (void)hipEventDestroy(e);
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
     delete h;
