@@ -284,7 +284,7 @@ int scaldpc_qary_into_llr(const float *pmf, int64_t rows, int32_t Q, uint32_t fl
  * (SCALDPC_QARY_NO_TREE); "dp" = 1 (default) the same shape's check update as a min-plus recursion over the edges in the
  * reference's order of additions -- no enumeration, the reference's messages bit for bit (scaldpc_qary_special.h) --
  * for calls of at least "dp_min" codewords (default 5; below, the tree walk), the row's edges split over four waves up
- * to "dp_split" codewords (default 192) | 0 off; "llr_tiled", "var_small": forms of the conversion / variable kernels;
+ * to "dp_split" codewords (default 64) and over two up to "dp_split2" (default 192) | 0 off; "llr_tiled", "var_small": forms of the conversion / variable kernels;
  * "timing" = 1: bracket the launches of a call with HIP events (scaldpc_qary_last_timing). */
 int scaldpc_qary_configure(scaldpc_qary *h, const char *key, const char *value);
 /* Measurement aid for bench.py (the q-ary counterpart of scaldpc_bp_time_kernels): after

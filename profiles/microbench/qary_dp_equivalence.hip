@@ -4,7 +4,7 @@
 //          assignment forms S left to right and lowers beta_j[d_j] with S - a_j[d_j], f32::min semantics)
 //   lane   k_q_special_check       the product's enumeration in the same form (codeword per lane)
 //   tree   k_q_special_check_tree  the product's tree walk in min-marginal form
-//   dp     k_q_special_check_dp    the product's min-plus recursion (no enumeration), whole row per lane and split over four waves
+//   dp     k_q_special_check_dp    the product's min-plus recursion (no enumeration), whole row per lane and split over two / four waves
 // all four kernels included from the product's header as it stands.  Inputs: smooth random LLRs over 20 binades (every
 // addition rounds), heavy ties, impossible symbols (+inf), NaN alphas (the variable update's inf - inf), zeros, sums that
 // overflow to +inf.  A difference is a bug in the kernel or a hole in the monotonicity argument of the header.
@@ -160,7 +160,7 @@ int main()
     const char *names[6] = {"smooth", "ties", "impossible", "nan", "zeros", "overflow"};
     int bad_total = 0;
     for (int flavour = 0; flavour < 6; flavour++) {
-        std::vector<float> in(n, 7.0f), host(n), out[4];
+        std::vector<float> in(n, 7.0f), host(n), out[5];
         for (int c = 0; c < R; c++)
             for (long b = 0; b < BATCH; b++) {
                 for (int j = 0; j < NB; j++)
@@ -179,7 +179,7 @@ int main()
                     for (int q = 0; q < QB; q++) host[at(c, j, q, b)] = bb[j * QB + q];
                 for (int q = 0; q < QS; q++) host[at(c, NB, q, b)] = bs[q];
             }
-        for (int k = 0; k < 4; k++) {
+        for (int k = 0; k < 5; k++) {
             HIPOK(hipMemcpy(d_work, in.data(), sizeof(float) * n, hipMemcpyHostToDevice));
             if (k == 0) {
                 const size_t lds = (size_t)2 * (NB * QB + QS) * 4 * 64;
@@ -188,17 +188,20 @@ int main()
                 const size_t lds = ((size_t)NB * QB + QS + (size_t)(NB * QB + QS) * 64) * 4;
                 hipLaunchKernelGGL((k_q_special_check_tree<QB, NB>), dim3(R, BATCH), dim3(64), lds, 0, d_row_ptr, d_work, BSUM, W, Bp);
             } else if (k == 2)
-                hipLaunchKernelGGL((k_q_special_check_dp<QB, NB, false>), dim3(R, Bp / 64), dim3(64), 0, 0, d_row_ptr, d_work, BSUM, W, Bp,
+                hipLaunchKernelGGL((k_q_special_check_dp<QB, NB, 1>), dim3(R, Bp / 64), dim3(64), 0, 0, d_row_ptr, d_work, BSUM, W, Bp,
+                                   BATCH);
+            else if (k == 3)
+                hipLaunchKernelGGL((k_q_special_check_dp<QB, NB, 4>), dim3(R, Bp / 64), dim3(256), 0, 0, d_row_ptr, d_work, BSUM, W, Bp,
                                    BATCH);
             else
-                hipLaunchKernelGGL((k_q_special_check_dp<QB, NB, true>), dim3(R, Bp / 64), dim3(256), 0, 0, d_row_ptr, d_work, BSUM, W, Bp,
+                hipLaunchKernelGGL((k_q_special_check_dp<QB, NB, 2>), dim3(R, Bp / 64), dim3(128), 0, 0, d_row_ptr, d_work, BSUM, W, Bp,
                                    BATCH);
             HIPOK(hipGetLastError());
             HIPOK(hipDeviceSynchronize());
             out[k].resize(n);
             HIPOK(hipMemcpy(out[k].data(), d_work, sizeof(float) * n, hipMemcpyDeviceToHost));
         }
-        long cnt = 0, diff[4] = {0, 0, 0, 0}, inf_out = 0;
+        long cnt = 0, diff[5] = {0, 0, 0, 0, 0}, inf_out = 0;
         for (int c = 0; c < R; c++)
             for (long b = 0; b < BATCH; b++)
                 for (int j = 0; j <= NB; j++)
@@ -208,7 +211,7 @@ int main()
                         memcpy(&h, &host[i], 4);
                         cnt++;
                         inf_out += std::isinf(host[i]);
-                        for (int k = 0; k < 4; k++) {
+                        for (int k = 0; k < 5; k++) {
                             uint32_t g;
                             memcpy(&g, &out[k][i], 4);
                             if (g != h) {
@@ -218,9 +221,9 @@ int main()
                             }
                         }
                     }
-        printf("CASE %-10s %ld messages (%ld of them +inf): %ld differ in lane, %ld differ in tree, %ld differ in dp, %ld differ in split dp\n",
-               names[flavour], cnt, inf_out, diff[0], diff[1], diff[2], diff[3]);
-        bad_total += (int)(diff[0] + diff[1] + diff[2] + diff[3] != 0);
+        printf("CASE %-10s %ld messages (%ld of them +inf): %ld differ in lane, %ld differ in tree, %ld differ in dp, %ld differ in split dp, %ld differ in half-split dp\n",
+               names[flavour], cnt, inf_out, diff[0], diff[1], diff[2], diff[3], diff[4]);
+        bad_total += (int)(diff[0] + diff[1] + diff[2] + diff[3] + diff[4] != 0);
     }
     // ---- Decoder (Q = 3), rows of 1 .. 7 edges ----
     {

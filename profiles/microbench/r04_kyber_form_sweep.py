@@ -20,7 +20,8 @@ for batch in (1, 2, 4, 8, 12, 16, 24, 32, 48, 64, 96, 128, 192, 256, 512, 1024):
     pb = rng.dirichlet(np.ones(5), size=(batch, 768)).astype(np.float32)
     ps = rng.dirichlet(np.ones(25), size=(batch, 512)).astype(np.float32)
     row, outs = {}, {}
-    for form, kn in (("tree", dict(dp=0)), ("dp", dict(dp=1, dp_min=1, dp_split=0)), ("split", dict(dp=1, dp_min=1, dp_split=1 << 20))):
+    for form, kn in (("tree", dict(dp=0)), ("dp", dict(dp=1, dp_min=1, dp_split=0, dp_split2=0)), ("half", dict(dp=1, dp_min=1, dp_split=0, dp_split2=1 << 20)),
+                     ("split", dict(dp=1, dp_min=1, dp_split=1 << 20))):
         dec.configure(timing=1, **kn)
         best = None
         for _ in range(6):
@@ -29,8 +30,9 @@ for batch in (1, 2, 4, 8, 12, 16, 24, 32, 48, 64, 96, 128, 192, 256, 512, 1024):
             if best is None or t["ms_loop"] < best["ms_loop"]:
                 best = t
         row[form] = best
-    assert np.array_equal(outs["tree"], outs["dp"]) and np.array_equal(outs["tree"], outs["split"])
+    assert np.array_equal(outs["tree"], outs["dp"]) and np.array_equal(outs["tree"], outs["split"]) and np.array_equal(outs["tree"], outs["half"])
     print(f"batch {batch:5d}  tree: loop {row['tree']['ms_loop']:.3f} ms (check {row['tree']['ms_check']:.3f})   "
           f"min-plus, row per lane: loop {row['dp']['ms_loop']:.3f} ms (check {row['dp']['ms_check']:.3f})   "
+          f"min-plus, row over two waves: loop {row['half']['ms_loop']:.3f} ms (check {row['half']['ms_check']:.3f})   "
           f"min-plus, row over four waves: loop {row['split']['ms_loop']:.3f} ms (check {row['split']['ms_check']:.3f})   same symbols", flush=True)
 dec.close()

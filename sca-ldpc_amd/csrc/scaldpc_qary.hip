@@ -648,7 +648,8 @@ struct scaldpc_qary {
     int kn_tree = 1;     // special decoder: tree-walk check kernel for the Kyber shape (QB = 5, 6 coefficient edges)
     int kn_dp = 1;       // special decoder, same shape: min-plus recursion instead of the enumeration (k_q_special_check_dp); batches >= kn_dp_min
     int kn_dp_min = 5;      // (below, one wave per (check, codeword) of the tree walk is as fast or faster: profiles/r04/kyber_form_sweep.log)
-    int kn_dp_split = 192;  // up to this batch the row's edges are split over four waves (same log)
+    int kn_dp_split = 64;    // up to this batch the row's edges are split over four waves (same log)
+    int kn_dp_split2 = 192;  // ... and up to this one over two
     // measurement aid (bench.py): with "timing" = 1 every check / variable launch of a call is bracketed by HIP events
     // on the launch stream; scaldpc_qary_last_timing reads the sums.  Off by default: the product path records nothing.
     int kn_llr_tiled = 1;  // probability -> LLR conversion through an LDS tile (coalesced reads); A/B knob "llr_tiled"
@@ -902,10 +903,13 @@ int qary_run(scaldpc_qary *h, const float *pmf_b, const float *pmf_s, int batch,
 #undef QUNROLLED
             else if (h->special && dp_nb) {
                 if (batch <= h->kn_dp_split)  // (a few dozen codewords: four waves per (check, 64 codewords))
-                    hipLaunchKernelGGL((k_q_special_check_dp<5, 6, true>), dim3(h->R, Bp / 64), dim3(256), 0, s, h->d_row_ptr, h->d_msg,
+                    hipLaunchKernelGGL((k_q_special_check_dp<5, 6, 4>), dim3(h->R, Bp / 64), dim3(256), 0, s, h->d_row_ptr, h->d_msg,
+                                       h->BSUM, h->W, Bp, batch);
+                else if (batch <= h->kn_dp_split2)  // (a few hundred: two)
+                    hipLaunchKernelGGL((k_q_special_check_dp<5, 6, 2>), dim3(h->R, Bp / 64), dim3(128), 0, s, h->d_row_ptr, h->d_msg,
                                        h->BSUM, h->W, Bp, batch);
                 else
-                    hipLaunchKernelGGL((k_q_special_check_dp<5, 6, false>), dim3(h->R, Bp / 64), dim3(64), 0, s, h->d_row_ptr, h->d_msg,
+                    hipLaunchKernelGGL((k_q_special_check_dp<5, 6, 1>), dim3(h->R, Bp / 64), dim3(64), 0, s, h->d_row_ptr, h->d_msg,
                                        h->BSUM, h->W, Bp, batch);
                 if (h->mindc - 1 != dp_nb || h->maxdc - 1 != dp_nb)
                     hipLaunchKernelGGL(k_q_special_check_wave, dim3(h->R, batch), dim3(64), wave_lds, s, h->d_row_ptr, h->d_msg,
@@ -1076,6 +1080,8 @@ int scaldpc_qary_configure(scaldpc_qary *h, const char *key, const char *value)
         h->kn_dp_min = std::max(1, atoi(value));
     else if (!strcmp(key, "dp_split"))
         h->kn_dp_split = std::max(0, atoi(value));
+    else if (!strcmp(key, "dp_split2"))
+        h->kn_dp_split2 = std::max(0, atoi(value));
     else if (!strcmp(key, "timing"))
         h->kn_timing = atoi(value) != 0;
     else if (!strcmp(key, "llr_tiled"))

@@ -389,16 +389,17 @@ struct DpEdge {
     }
 };
 
-// SPLIT = false: grid (R, Bp / 64), block 64 -- a lane does the whole row of its codeword.
-// SPLIT = true:  grid (R, Bp / 64), block 256 -- the four waves of a block share ONE (check, 64 codewords) and split its
+// PARTS = 1: grid (R, Bp / 64), block 64 -- a lane does the whole row of its codeword.
+// PARTS = 2: block 128 -- two waves share a (check, 64 codewords): edges {0, 3, 4} and {1, 2, 5, row-sum}.
+// PARTS = 4: grid (R, Bp / 64), block 256 -- the four waves of a block share ONE (check, 64 codewords) and split its
 // edges: wave 0 pins edge 0, wave 1 edge 1, wave 2 edges 2 and 5 and writes the row-sum variable's messages, wave 3 edges 3
 // and 4 (about a quarter of the additions each; a wave's prefix recursion up to its first edge is cheap next to the pinned
-// ones).  Four times the waves of a quarter the length: what a call of a few dozen codewords needs to fill the chip (the
-// launch is then 12 us, close to the empty-launch floor of this loop); from ~200 codewords on the whole-row form has
-// waves enough and less redundant work (profiles/r04/kyber_form_sweep.log).  The messages are updated in place, so with
-// SPLIT every wave loads the whole row before the block's barrier and stores after it.
-template <int QB, int NB, bool SPLIT>
-__global__ __launch_bounds__(SPLIT ? 256 : 64) void k_q_special_check_dp(const int *__restrict__ row_ptr, float *msg, int BSUM, int W,
+// ones).  Four times the waves of a quarter the length: what a call of up to 64 codewords needs to fill the chip (the
+// launch is then 12 us, close to the empty-launch floor of this loop); halves are best from 65 to ~192 codewords, and from
+// there on the whole-row form has waves enough and less redundant work (profiles/r04/kyber_form_sweep.log).  The messages are updated in place, so with
+// PARTS > 1 every wave loads the whole row before the block's barrier and stores after it.
+template <int QB, int NB, int PARTS>
+__global__ __launch_bounds__(64 * PARTS) void k_q_special_check_dp(const int *__restrict__ row_ptr, float *msg, int BSUM, int W,
                                                                           long Bp, int batch)
 {
     static_assert(NB == 6, "the split of the edges over the four waves below is written for six coefficient edges");
@@ -417,18 +418,24 @@ __global__ __launch_bounds__(SPLIT ? 256 : 64) void k_q_special_check_dp(const i
     float *const sum_top = msg + ((size_t)(e0 + NB) * W + top) * Bp + b;
 #pragma unroll
     for (int w = 0; w < WN; w++) asw[w] = *(sum_top - (ptrdiff_t)w * (ptrdiff_t)Bp);
-    if constexpr (SPLIT) __syncthreads();
+    if constexpr (PARTS > 1) __syncthreads();
     const bool store = b < batch;
     float *const edge0 = msg + (size_t)e0 * W * Bp + b;
     const float P0[1] = {0.0f};  // S starts at 0 (decoder_special.rs:536)
-    if (store && (!SPLIT || part == 2)) {
+    if (store && part == PARTS / 2) {  // (the wave that writes the row-sum variable's messages)
         // row-sum symbols no assignment reaches keep the reference's initial +inf (decoder_special.rs:527)
         for (int t = 0; t < top - (WN - 1); t++) msg[((size_t)(e0 + NB) * W + t) * Bp + b] = INFINITY;
         for (int t = top + 1; t < 2 * BSUM + 1; t++) msg[((size_t)(e0 + NB) * W + t) * Bp + b] = INFINITY;
     }
-    if constexpr (!SPLIT)
+    static_assert(PARTS == 1 || PARTS == 2 || PARTS == 4, "whole row, halves or quarters");
+    if constexpr (PARTS == 1)
         DpEdge<QB, NB, 0, 1, 0x7Fu>::run(P0, a, asw, edge0, (size_t)Bp, (size_t)W * Bp, sum_top, store);
-    else if (part == 0)
+    else if constexpr (PARTS == 2) {
+        if (part == 0)
+            DpEdge<QB, NB, 0, 1, 0x19u>::run(P0, a, asw, edge0, (size_t)Bp, (size_t)W * Bp, sum_top, store);  // edges 0, 3, 4
+        else
+            DpEdge<QB, NB, 0, 1, 0x66u>::run(P0, a, asw, edge0, (size_t)Bp, (size_t)W * Bp, sum_top, store);  // edges 1, 2, 5, row-sum
+    } else if (part == 0)
         DpEdge<QB, NB, 0, 1, 0x01u>::run(P0, a, asw, edge0, (size_t)Bp, (size_t)W * Bp, sum_top, store);
     else if (part == 1)
         DpEdge<QB, NB, 0, 1, 0x02u>::run(P0, a, asw, edge0, (size_t)Bp, (size_t)W * Bp, sum_top, store);

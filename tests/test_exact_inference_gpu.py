@@ -131,7 +131,7 @@ def test_qary_min_sum_finds_the_minimum_cost_assignment(B, knobs):
         assert np.array_equal(got, best), (seed, knobs)
 
 
-@pytest.mark.parametrize("knobs", [dict(), dict(dp_min=1, dp_split=0), dict(dp_min=1, dp_split=1 << 20), dict(dp=0), dict(dp=0, tree=0), dict(wave=0), dict(wave=0, tree=0)])
+@pytest.mark.parametrize("knobs", [dict(), dict(dp_min=1, dp_split=0, dp_split2=0), dict(dp_min=1, dp_split=0, dp_split2=1 << 20), dict(dp_min=1, dp_split=1 << 20), dict(dp=0), dict(dp=0, tree=0), dict(wave=0), dict(wave=0, tree=0)])
 def test_special_decoder_finds_the_minimum_cost_assignment(knobs):
     """DecoderSpecial, B = 2, BSUM = 12 (DecoderN*R*SW6, lib.rs:54-75) on cycle-free [H' | +-I]; rows of 6
     coefficient edges go through the tree-walk kernel, the others through the wave / lane forms."""
@@ -161,7 +161,7 @@ def test_qary_large_tree(B, knobs):
     assert ok.mean() > 0.9 and np.array_equal(got[ok], dec_exact[ok])
 
 
-@pytest.mark.parametrize("knobs", [dict(), dict(dp_min=1, dp_split=0), dict(dp_min=1, dp_split=1 << 20), dict(dp=0), dict(dp=0, tree=0), dict(wave=0), dict(var_small=0, llr_tiled=0)])
+@pytest.mark.parametrize("knobs", [dict(), dict(dp_min=1, dp_split=0, dp_split2=0), dict(dp_min=1, dp_split=0, dp_split2=1 << 20), dict(dp_min=1, dp_split=1 << 20), dict(dp=0), dict(dp=0, tree=0), dict(wave=0), dict(var_small=0, llr_tiled=0)])
 def test_special_large_tree(knobs):
     """DecoderSpecial (B = 2, BSUM = 12) on a cycle-free [H' | +-I] of 40 checks with 2-6 coefficient edges each: symbols =
     arg-minima of the exact min-marginals wherever those are clear; tree-walk, wave and lane kernels; 66 channel outputs."""

@@ -167,9 +167,9 @@ def test_registered_n1024r256sw6(oracle, golden, batch):
     dec = qary.decoder_class("DecoderN1024R256SW6")(H, 3)
     assert (dec.N, dec.R, dec.B, dec.BSUM, dec.DC) == (1024, 256, 2, 12, 7)
     # the library's choice, min-plus recursion (whole row per lane / row split over four waves), tree walk, generic wave kernel, lane kernel
-    for kn in (dict(), dict(dp_min=1, dp_split=0), dict(dp_min=1, dp_split=1 << 20), dict(dp=0), dict(wave=1, dp=0), dict(wave=1, tree=0, dp=0),
+    for kn in (dict(), dict(dp_min=1, dp_split=0, dp_split2=0), dict(dp_min=1, dp_split=0, dp_split2=1 << 20), dict(dp_min=1, dp_split=1 << 20), dict(dp=0), dict(wave=1, dp=0), dict(wave=1, tree=0, dp=0),
                dict(wave=0, tree=0, dp=0)):
-        dec.configure(**{**dict(wave=-1, tree=1, dp=1, dp_min=5, dp_split=192), **kn})
+        dec.configure(**{**dict(wave=-1, tree=1, dp=1, dp_min=5, dp_split=64, dp_split2=192), **kn})
         got = dec.min_sum_batch(pb, ps)
         assert np.array_equal(got, ref), kn
     dec.close()
@@ -290,7 +290,7 @@ def test_special_check_kernels_equal_the_enumeration_bit_for_bit():
     r = subprocess.run([os.path.join(d, "qary_dp_equivalence")], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("CASE")]
-    assert len(lines) == 6 and all(" 0 differ in lane, 0 differ in tree, 0 differ in dp, 0 differ in split dp" in ln for ln in lines), r.stdout
+    assert len(lines) == 6 and all(" 0 differ in lane, 0 differ in tree, 0 differ in dp, 0 differ in split dp, 0 differ in half-split dp" in ln for ln in lines), r.stdout
     # second part: Decoder's check update at Q = 3, rows of 1 .. 7 edges (config 4's decoder) -- host enumeration over the finite
     # supports (decoder.rs:585-631) against k_q_check_unrolled<3,7> and the clipped min-plus recursion k_q_check_dp<3,7>,
     # messages and the error code of the pass (the program's exit code covers the codes)
@@ -366,7 +366,8 @@ def test_special_tree_kernel_with_mixed_row_degrees_and_impossible_symbols(oracl
     with np.errstate(divide="ignore"):
         ref = oracle.qary_special_batch(g, B, BSUM, pb, ps, 3, threads=8)
         out = {}
-        for name, kn in (("dp", dict(wave=-1, tree=1, dp=1, dp_min=1, dp_split=0)), ("dp split", dict(wave=-1, tree=1, dp=1, dp_min=1, dp_split=1 << 20)),
+        for name, kn in (("dp", dict(wave=-1, tree=1, dp=1, dp_min=1, dp_split=0, dp_split2=0)), ("dp halves", dict(wave=-1, tree=1, dp=1, dp_min=1, dp_split=0, dp_split2=1 << 20)),
+                         ("dp quarters", dict(wave=-1, tree=1, dp=1, dp_min=1, dp_split=1 << 20)),
                          ("tree", dict(wave=-1, tree=1, dp=0)), ("generic", dict(wave=1, tree=0, dp=0)), ("lane", dict(wave=0, tree=0, dp=0))):
             dec.configure(**kn)
             out[name] = dec.min_sum_batch(pb, ps)

@@ -65,7 +65,7 @@ def test_random_qary_instances(oracle, R, N, dc, B, batch, iters, seed, zero_fra
           suppress_health_check=list(HealthCheck))
 @given(R=st.integers(2, 9), NB=st.integers(8, 30), batch=st.sampled_from([1, 3, 40, 70, 130]), iters=st.integers(1, 5),
        seed=st.integers(0, 9999), zero_frac=st.sampled_from([0.0, 0.1, 0.3]), full=st.booleans(),
-       form=st.sampled_from(["dp", "dp split", "tree", "wave", "lane"]), var_small=st.integers(0, 1))
+       form=st.sampled_from(["dp", "dp halves", "dp quarters", "tree", "wave", "lane"]), var_small=st.integers(0, 1))
 def test_random_special_instances(oracle, R, NB, batch, iters, seed, zero_frac, full, form, var_small):
     """DecoderSpecial at the Kyber alphabets (B = 2, BSUM = 12) on random H = [H' | I]: rows of six coefficient edges (the
     min-plus recursion `k_q_special_check_dp` / the tree walk) mixed with shorter rows (generic wave kernel), signed
@@ -95,8 +95,9 @@ def test_random_special_instances(oracle, R, NB, batch, iters, seed, zero_frac, 
         ps[zs] = 0.0
         ps /= ps.sum(axis=2, keepdims=True)
     dec = qary.decoder_class(f"DecoderN{NB + R}R{R}SW{SW}")(H, iters)
-    dec.configure(var_small=var_small, **{"dp": dict(wave=-1, tree=1, dp=1, dp_min=1, dp_split=0),
-                                          "dp split": dict(wave=-1, tree=1, dp=1, dp_min=1, dp_split=1 << 20), "tree": dict(wave=-1, tree=1, dp=0),
+    dec.configure(var_small=var_small, **{"dp": dict(wave=-1, tree=1, dp=1, dp_min=1, dp_split=0, dp_split2=0),
+                                          "dp halves": dict(wave=-1, tree=1, dp=1, dp_min=1, dp_split=0, dp_split2=1 << 20),
+                                          "dp quarters": dict(wave=-1, tree=1, dp=1, dp_min=1, dp_split=1 << 20), "tree": dict(wave=-1, tree=1, dp=0),
                                           "wave": dict(wave=1, tree=0, dp=0), "lane": dict(wave=0, tree=0, dp=0)}[form])
     with np.errstate(divide="ignore", invalid="ignore"):
         ref = oracle.qary_special_batch(g, B, BSUM, pb, ps, iters, threads=8)
