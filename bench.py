@@ -408,8 +408,10 @@ def main():
         try:
             group_bytes = 4.0 * E * swept * lanes
             out["roofline"]["cache_ceiling_GBps"] = lib.measure_rmw_stream(int(group_bytes), 51, 50)
-            out["roofline"]["cache_ceiling_what"] = ("in-place read-all / write-all stream (51 rows of 256 B per wave) over %.0f MB = the "
-                                                     "tile group's message array: the Infinity-Cache regime" % (group_bytes / 1e6))
+            out["roofline"]["cache_ceiling_what"] = ("in-place read-all / write-all stream (51 rows of 256 B per wave, the row in registers: every "
+                                                     "load issued before the first use, as the row kernels do) over %.0f MB = the tile group's "
+                                                     "message array: the Infinity-Cache regime; any read : write mix of this shape measures the "
+                                                     "same total (profiles/r04/stream_modes.log)" % (group_bytes / 1e6))
             out["roofline"]["hbm_rmw_ceiling_GBps"] = lib.measure_rmw_stream(int(16 * group_bytes), 51, 6)
             out["roofline"]["frac_of_cache_ceiling"] = moved / out["roofline"]["cache_ceiling_GBps"]
         except Exception as ex:  # (a measurement aid must not cost the run its line)
@@ -435,6 +437,8 @@ def main():
               "whole_step_frac_le_1": out["roofline"]["whole_step"]["frac"] <= 1.0}
         if hbm_stream:
             sc["hbm_streaming_le_copy_ceiling"] = hbm_stream["moved_GBps"] <= 1.08 * copy_gbs
+        if out["roofline"].get("cache_ceiling_GBps"):  # the pair cannot beat a plain stream over the same cache-resident bytes
+            sc["pair_le_cache_ceiling"] = moved <= 1.04 * out["roofline"]["cache_ceiling_GBps"]
         out["roofline"]["self_check"] = sc
         if not all(sc.values()):
             print(f"bench.py: roofline self-check failed: {sc}", file=sys.stderr)
