@@ -375,6 +375,40 @@ def test_special_tree_kernel_with_mixed_row_degrees_and_impossible_symbols(oracl
         assert np.array_equal(o, ref), name
 
 
+@pytest.mark.parametrize("batch", [3, 70, 200])
+def test_special_decoder_with_a_wider_row_sum_alphabet(oracle, batch):
+    """DecoderSpecial only asks SW * B <= BSUM and BSUM % B == 0 (decoder_special.rs:388-392); the registered Kyber classes sit
+    at equality (BSUM = 12).  With BSUM = 14 the row-sum alphabet has symbols NO assignment of a six-edge check reaches: the
+    min-plus kernels write the reference's initial +inf there, the enumerating kernels never touch their +inf -- every form
+    against the oracle (rows of 3 .. 6 coefficient edges, impossible symbols on both alphabets)."""
+    rng = np.random.RandomState(300 + batch)
+    R, NB, B, SW, BSUM = 10, 36, 2, 6, 14
+    Hp = np.zeros((R, NB), dtype=np.int8)
+    for r in range(R):
+        k = 6 if r % 4 else rng.randint(3, 6)
+        cols = rng.choice(NB, k, replace=False)
+        Hp[r, cols] = rng.choice([-1, 1], size=k)
+    H = np.concatenate([Hp, np.eye(R, dtype=np.int8)], axis=1)
+    g = S.TannerGraph.from_dense(H)
+    pb = rng.dirichlet(np.ones(5) * 0.7, size=(batch, NB)).astype(np.float32)
+    ps = rng.dirichlet(np.ones(2 * BSUM + 1) * 0.7, size=(batch, R)).astype(np.float32)
+    zs = rng.rand(batch, R, 2 * BSUM + 1) < 0.1
+    zs[..., BSUM] = False
+    ps[zs] = 0.0
+    ps /= ps.sum(axis=2, keepdims=True)
+    base = qary.decoder_class(f"DecoderN{NB + R}R{R}SW{SW}")
+    wide = type("DecoderSpecialWideSum", (base,), dict(BSUM=BSUM, QS=2 * BSUM + 1))
+    dec = wide(H, 3)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        ref = oracle.qary_special_batch(g, B, BSUM, pb, ps, 3, threads=8)
+        for name, kn in (("dp", dict(wave=-1, tree=1, dp=1, dp_min=1, dp_split=0, dp_split2=0)), ("dp halves", dict(wave=-1, tree=1, dp=1, dp_min=1, dp_split=0, dp_split2=1 << 20)),
+                         ("dp quarters", dict(wave=-1, tree=1, dp=1, dp_min=1, dp_split=1 << 20)), ("tree", dict(wave=-1, tree=1, dp=0)),
+                         ("generic", dict(wave=1, tree=0, dp=0)), ("lane", dict(wave=0, tree=0, dp=0))):
+            dec.configure(**kn)
+            assert np.array_equal(dec.min_sum_batch(pb, ps), ref), name
+    dec.close()
+
+
 def test_device_pointer_calls_equal_host_buffer_calls(oracle, golden):
     """SCALDPC_F_DEVICE_IO on both q-ary entry points (what bench.py times: channel outputs resident in HBM, symbols
     left in HBM): same symbols as the host-buffer call and as the oracle, on the caller's stream; a ragged batch
