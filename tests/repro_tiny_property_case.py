@@ -1,6 +1,9 @@
+"""Test tooling (not collected by pytest): the tiny dense instance on which a 15 000-example soak of tests/test_bp_property_gpu.py found the
+property test's tolerance too tight in round 4 (a 3000x chaotic amplification of one-ulp perturbations in the f32 tanh rule) -- HIP path
+against the oracle, with the perturbation experiment that sized the new tolerance.  Lives under tests/ because it calls the oracle."""
 import importlib, sys, os
 import numpy as np
-sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo")); sys.path.insert(0, os.path.join(sys.path[0], "tests"))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 S = importlib.import_module("sca-ldpc_amd"); bp = importlib.import_module("sca-ldpc_amd.bp")
 from oracle import pyoracle as oracle
 m, n, density, batch, max_iter, seed = 22, 23, 0.3267453472929817, 74, 10, 2
