@@ -86,15 +86,23 @@ __global__ void k_q_into_llr(const float *__restrict__ pmf, int nv, int Q, int b
 // With col_ptr != nullptr the wave also writes the variable's first variable-to-check messages (decoder.rs:567-573:
 // v2c = channel * h, i.e. the LLR row, mirrored where h < 0) to every edge of its variable -- k_q_init's job, without the
 // launch and without reading the LLRs back (vbase = index of this alphabet's first variable in the graph, W = message row width).
-__global__ void k_q_into_llr_tiled(const float *__restrict__ pmf, int nv, int Q, int VT, int batch, long Bp,
-                                   float *__restrict__ llr, int *__restrict__ err, u64 *__restrict__ first_bad, int kind,
+// A SECOND alphabet can ride in the same launch (DecoderSpecial: the coefficient rows and the row-sum rows): blocks nb0 .. of
+// grid.x convert pmf1 (nv1 rows of Q1 symbols, VT1 per block, kind 1, first variable vbase1) -- one launch less in a call
+// that is made of ~10 us launches; the block is sized for the larger VT, the waves beyond a segment's VT only help load.
+__global__ void k_q_into_llr_tiled(const float *__restrict__ pmf0, int nv0, int Q0, int VT0, int batch, long Bp,
+                                   float *__restrict__ llr0, int *__restrict__ err, u64 *__restrict__ first_bad, int kind0,
                                    const int *__restrict__ col_ptr = nullptr, const int *__restrict__ csc_edge = nullptr,
                                    const int *__restrict__ edge_h = nullptr, float *__restrict__ msg = nullptr, int W = 0,
-                                   int vbase = 0)
+                                   int vbase0 = 0, int nb0 = 0x7fffffff, const float *__restrict__ pmf1 = nullptr, int nv1 = 0,
+                                   int Q1 = 0, int VT1 = 0, float *__restrict__ llr1 = nullptr, int vbase1 = 0)
 {
     __shared__ float tile[64 * 33];
+    const bool seg1 = (int)blockIdx.x >= nb0;
+    const float *__restrict__ pmf = seg1 ? pmf1 : pmf0;
+    float *__restrict__ llr = seg1 ? llr1 : llr0;
+    const int nv = seg1 ? nv1 : nv0, Q = seg1 ? Q1 : Q0, VT = seg1 ? VT1 : VT0, kind = seg1 ? 1 : kind0, vbase = seg1 ? vbase1 : vbase0;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int v0 = blockIdx.x * VT;
+    const int v0 = ((int)blockIdx.x - (seg1 ? nb0 : 0)) * VT;
     const long b0 = (long)blockIdx.y * 64;
     const int nvv = min(VT, nv - v0), width = nvv * Q;  // floats per codeword in this tile (<= 32)
     // (all threads of the block over the tile's 64 x width floats: every load instruction has 64 active lanes)
@@ -834,11 +842,20 @@ int qary_run(scaldpc_qary *h, const float *pmf_b, const float *pmf_s, int batch,
             hipLaunchKernelGGL(k_q_into_llr, dim3(nv, Bp / TB), dim3(TB), 0, s, dp, nv, Q, batch, Bp, llr, h->d_err, h->d_first_bad,
                                kind);
     };
-    into_llr(dp_b, BV, h->Q, h->d_llr, 0);
-    SC_HIP(hipGetLastError());
-    if (h->special) {
-        into_llr(dp_s, h->R, h->QS, h->d_llr + (size_t)BV * h->Q * Bp, 1);
+    if (h->special && fused_init) {  // both alphabets in one launch
+        const int VT0 = std::max(1, 32 / h->Q), VT1 = std::max(1, 32 / h->QS), nb0 = (BV + VT0 - 1) / VT0, nb1 = (h->R + VT1 - 1) / VT1;
+        hipLaunchKernelGGL(k_q_into_llr_tiled, dim3(nb0 + nb1, Bp / 64), dim3(64 * std::max(VT0, VT1)), 0, s, dp_b, BV, h->Q, VT0, batch, Bp,
+                           h->d_llr, h->d_err, h->d_first_bad, 0, (const int *)h->d_col_ptr, (const int *)h->d_csc_edge,
+                           (const int *)h->d_edge_h, h->d_msg, h->W, 0, nb0, dp_s, h->R, h->QS, VT1,
+                           h->d_llr + (size_t)BV * h->Q * Bp, BV);
         SC_HIP(hipGetLastError());
+    } else {
+        into_llr(dp_b, BV, h->Q, h->d_llr, 0);
+        SC_HIP(hipGetLastError());
+        if (h->special) {
+            into_llr(dp_s, h->R, h->QS, h->d_llr + (size_t)BV * h->Q * Bp, 1);
+            SC_HIP(hipGetLastError());
+        }
     }
     if (h->E && !fused_init) {
         hipLaunchKernelGGL(k_q_init, dim3(h->E, Bp / TB), dim3(TB), 0, s, h->d_edge_var, h->d_edge_h, h->d_var_q,
