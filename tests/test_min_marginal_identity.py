@@ -180,3 +180,101 @@ def test_minplus_recursion_equals_the_enumeration_bit_for_bit():
         assert want_s.tobytes() == got_s.tobytes(), (kind, a, a_sum, want_s, got_s)
         compared += want.size + want_s.size
     assert compared > 7000
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The clipped recursion of k_q_check_dp (csrc/scaldpc_qary_rows.h) for Decoder's constraint (decoder.rs:585-631): the last
+# edge's symbol follows from sum d = 0, so an assignment exists only for free-digit sums U in [(K - 2) B, K B], and every table
+# keeps only the digit sums that can still reach that window.  The same windows (DpRange) restated here, against the
+# reference-form enumeration over the finite supports, bit for bit, rows of 2 .. 6 edges, alphabets of 3 and 5.
+# ---------------------------------------------------------------------------------------------------------------------
+def generic_check_enumerated(a, B):
+    """decoder.rs:585-631: finite symbols of the first K - 1 edges enumerated, the last follows; S left to right; an assignment
+    counts if its S is finite.  Returns (beta [K][Q], has_configuration)."""
+    import itertools
+
+    K, Q = a.shape
+    beta = np.full((K, Q), np.inf, dtype=np.float32)
+    fin = [[q for q in range(Q) if np.isfinite(a[j, q])] for j in range(K)]
+    nconf = 0
+    with np.errstate(invalid="ignore", over="ignore"):
+        for qs in itertools.product(*fin[: K - 1]):
+            dl = -sum(q - B for q in qs)
+            if not -B <= dl <= B:
+                continue
+            S = np.float32(0.0)
+            for j, q in enumerate(qs):
+                S = np.float32(S + a[j, q])
+            S = np.float32(S + a[K - 1, dl + B])
+            if not np.isfinite(S):
+                continue
+            nconf += 1
+            for j, q in enumerate(qs + (dl + B,)):
+                beta[j, q] = min(beta[j, q], np.float32(S - a[j, q]))
+    return beta, nconf > 0
+
+
+def generic_check_minplus_clipped(a, B):
+    K, Q = a.shape
+    NB, S_, TL, TH = K - 1, Q - 1, (K - 2) * B, K * B
+    plo = lambda k: max(0, TL - (NB - k) * S_)  # noqa: E731  (prefix over k edges)
+    phi = lambda k: min(k * S_, TH)  # noqa: E731
+    vlo = lambda k, d: max(0, TL - d - (NB - k) * S_)  # noqa: E731  (pinned to d, k edges done)
+    vhi = lambda k, d: min((k - 1) * S_, TH - d)  # noqa: E731
+
+    def step(tab, lo_in, ak, lo_out, hi_out):
+        out = np.full(hi_out - lo_out + 1, np.inf, dtype=np.float32)
+        with np.errstate(invalid="ignore", over="ignore"):
+            for u in range(lo_out, hi_out + 1):
+                c = [np.float32(tab[u - q - lo_in] + ak[q]) for q in range(Q) if 0 <= u - q - lo_in < tab.size]
+                c = [x for x in c if not np.isnan(x)]
+                out[u - lo_out] = min(c) if c else np.float32(np.nan)
+        return out
+
+    beta = np.full((K, Q), np.inf, dtype=np.float32)
+    P = np.zeros(1, dtype=np.float32)  # prefix over 0 edges: digit sum 0
+    with np.errstate(invalid="ignore", over="ignore"):
+        for j in range(NB):
+            for d in range(Q):
+                lo, hi = vlo(j + 1, d), vhi(j + 1, d)
+                M = np.float32(np.inf)
+                if hi >= lo:
+                    V = np.array([np.float32(P[u - plo(j)] + a[j, d]) for u in range(lo, hi + 1)], dtype=np.float32)
+                    dead = False
+                    for k in range(j + 1, NB):
+                        lo2, hi2 = vlo(k + 1, d), vhi(k + 1, d)
+                        if hi2 < lo2:
+                            dead = True
+                            break
+                        V, lo, hi = step(V, lo, a[k], lo2, hi2), lo2, hi2
+                    if not dead:
+                        c = [np.float32(V[u - lo] + a[K - 1, K * B - u - d]) for u in range(lo, hi + 1)]
+                        c = [x for x in c if not np.isnan(x)]
+                        M = min(c) if c else np.float32(np.nan)
+                beta[j, d] = np.float32(M - a[j, d]) if np.isfinite(M) else np.float32(np.inf)
+            P = step(P, plo(j), a[j], plo(j + 1), phi(j + 1))
+        any_conf = False
+        for ql in range(Q):
+            U = K * B - ql
+            M = np.float32(P[U - plo(NB)] + a[K - 1, ql]) if plo(NB) <= U <= phi(NB) else np.float32(np.inf)
+            any_conf |= bool(np.isfinite(M))
+            beta[K - 1, ql] = np.float32(M - a[K - 1, ql]) if np.isfinite(M) else np.float32(np.inf)
+    return beta, any_conf
+
+
+def test_clipped_minplus_recursion_equals_the_enumeration_bit_for_bit():
+    rng = np.random.RandomState(9)
+    compared = 0
+    for trial in range(420):
+        kind = trial % 6
+        B = 1 + (trial // 6) % 2
+        K = 2 + (trial // 12) % 5
+        a = _draw(rng, (K, 2 * B + 1), kind)
+        if any(not np.isfinite(a[j]).any() for j in range(K)):
+            continue  # (an edge without a finite symbol: the reference would not terminate, the kernels report it)
+        want, conf = generic_check_enumerated(a, B)
+        got, conf2 = generic_check_minplus_clipped(a, B)
+        assert conf == conf2, (kind, a)
+        assert want.tobytes() == got.tobytes(), (kind, K, B, a, want, got)
+        compared += want.size
+    assert compared > 4000
